@@ -1,0 +1,312 @@
+"""ctypes binding of libgunrock.so.
+
+Struct layouts mirror include/gunrock/gunrock.h (reference gunrock/gunrock.h:51-99) field by field.
+No compute happens in Python and nothing here falls back to a CPU implementation: if the HIP
+library is missing, :func:`lib` raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libgunrock.so")
+_LIB = None
+
+# enum VertexIdType / SizeTType / ValueType / SrcMode (gunrock.h)
+VTXID_INT = 0
+SIZET_INT = 0
+VALUE_INT, VALUE_UINT, VALUE_FLOAT = 0, 1, 2
+SRC_MANUALLY, SRC_RANDOMIZE, SRC_LARGEST_DEGREE = 0, 1, 2
+
+i32p = C.POINTER(C.c_int32)
+
+
+class GunrockDataType(C.Structure):
+    _fields_ = [("VTXID_TYPE", C.c_int), ("SIZET_TYPE", C.c_int), ("VALUE_TYPE", C.c_int)]
+
+
+class GunrockGraph(C.Structure):
+    _fields_ = [("num_nodes", C.c_size_t), ("num_edges", C.c_size_t),
+                ("row_offsets", C.c_void_p), ("col_indices", C.c_void_p),
+                ("col_offsets", C.c_void_p), ("row_indices", C.c_void_p),
+                ("node_values", C.c_void_p), ("edge_values", C.c_void_p)]
+
+
+class GunrockConfig(C.Structure):
+    _fields_ = [("mark_pred", C.c_bool), ("idempotence", C.c_bool),
+                ("src_node", C.c_int), ("device", C.c_int), ("max_iter", C.c_int),
+                ("top_nodes", C.c_int), ("delta_factor", C.c_int),
+                ("delta", C.c_float), ("error", C.c_float), ("queue_size", C.c_float),
+                ("src_mode", C.c_int)]
+
+
+def build_library(force=False):
+    """Compile libgunrock.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_PKG, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src_dir, "clean"])
+    subprocess.check_call(["make", "-C", src_dir, "-j8", "-s"])
+    return LIB_PATH
+
+
+# every symbol declared in include/gunrock/*.h (tests/test_capi_symbols.py checks the list against the headers)
+_SIGNATURES = {
+    "gunrock_bfs_func": (None, [C.POINTER(GunrockGraph), C.POINTER(GunrockGraph), GunrockConfig, GunrockDataType]),
+    "gunrock_bc_func": (None, [C.POINTER(GunrockGraph), C.POINTER(GunrockGraph), GunrockConfig, GunrockDataType]),
+    "gunrock_cc_func": (None, [C.POINTER(GunrockGraph), C.POINTER(GunrockGraph), GunrockConfig, GunrockDataType]),
+    "gunrock_sssp_func": (None, [C.POINTER(GunrockGraph), C.c_void_p, C.POINTER(GunrockGraph), GunrockConfig,
+                                 GunrockDataType]),
+    "gunrock_pr_func": (None, [C.POINTER(GunrockGraph), C.c_void_p, C.c_void_p, C.POINTER(GunrockGraph),
+                               GunrockConfig, GunrockDataType]),
+    "gunrock_topk_func": (None, [C.POINTER(GunrockGraph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(GunrockGraph), GunrockConfig, GunrockDataType]),
+    "grx_graph_from_market": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "grx_graph_rmat_libc": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [C.POINTER(C.c_void_p)]),
+    "grx_graph_rmat_seeded": (C.c_int, [C.c_int, C.c_longlong, C.c_uint64, C.c_int] + [C.c_double] * 4 +
+                              [C.POINTER(C.c_void_p)]),
+    "grx_graph_from_coo": (C.c_int, [C.c_int, C.c_longlong, i32p, i32p, i32p, C.POINTER(C.c_void_p)]),
+    "grx_graph_from_csr": (C.c_int, [C.c_int, C.c_int, i32p, i32p, i32p, C.POINTER(C.c_void_p)]),
+    "grx_graph_nodes": (C.c_int, [C.c_void_p]),
+    "grx_graph_edges": (C.c_int, [C.c_void_p]),
+    "grx_graph_row_offsets": (i32p, [C.c_void_p]),
+    "grx_graph_col_indices": (i32p, [C.c_void_p]),
+    "grx_graph_edge_values": (i32p, [C.c_void_p]),
+    "grx_graph_highest_degree_node": (C.c_int, [C.c_void_p, i32p]),
+    "grx_graph_average_degree": (C.c_int, [C.c_void_p]),
+    "grx_random_node": (C.c_int, [C.c_int]),
+    "grx_graph_free": (None, [C.c_void_p]),
+    "grx_rmat_seeded_device": (C.c_int, [C.c_int, C.c_longlong, C.c_longlong, C.c_uint64] + [C.c_double] * 4 +
+                               [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "grx_bfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
+    "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "grx_bfs_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "grx_bfs_extract": (C.c_int, [C.c_void_p, i32p, i32p]),
+    "grx_bfs_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "grx_bfs_destroy": (None, [C.c_void_p]),
+    "grx_bfs_count_visited": (None, [C.c_int, i32p, i32p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "grx_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    """Load libgunrock.so (once).  Raises if the HIP library has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "gunrockinst_amd: %s is missing -- build it with `make -C gunrockinst_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def version():
+    return lib().grx_version().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("gunrockinst_amd: %s failed (code %d)" % (what, rc))
+
+
+def _p(a):
+    return a.ctypes.data_as(i32p)
+
+
+class HostGraph:
+    """gunrock::Csr<int,int,int> built by the library's own host graph code."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        L = lib()
+        self.nodes = L.grx_graph_nodes(self._h)
+        self.edges = L.grx_graph_edges(self._h)
+
+    @classmethod
+    def from_market(cls, path, undirected=False, reversed_=False):
+        h = C.c_void_p()
+        _check(lib().grx_graph_from_market(os.fsencode(path), int(undirected), int(reversed_), C.byref(h)),
+               "BuildMarketGraph(%s)" % path)
+        return cls(h.value)
+
+    @classmethod
+    def rmat_libc(cls, nodes, edges, undirected=False, a=0.55, b=0.2, c=0.2, d=0.05):
+        h = C.c_void_p()
+        _check(lib().grx_graph_rmat_libc(nodes, edges, int(undirected), a, b, c, d, C.byref(h)), "BuildRmatGraph")
+        return cls(h.value)
+
+    @classmethod
+    def rmat_seeded(cls, scale, pairs, seed=0x6772, undirected=True, a=0.55, b=0.2, c=0.2, d=0.05):
+        h = C.c_void_p()
+        _check(lib().grx_graph_rmat_seeded(scale, pairs, seed, int(undirected), a, b, c, d, C.byref(h)),
+               "BuildSeededRmatGraph")
+        return cls(h.value)
+
+    @classmethod
+    def from_coo(cls, nodes, rows, cols, vals=None):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        v = None if vals is None else np.ascontiguousarray(vals, dtype=np.int32)
+        h = C.c_void_p()
+        _check(lib().grx_graph_from_coo(nodes, rows.shape[0], _p(rows), _p(cols), None if v is None else _p(v),
+                                        C.byref(h)), "Csr::FromCoo")
+        return cls(h.value)
+
+    @classmethod
+    def from_csr(cls, nodes, row_offsets, col_indices, edge_values=None):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        ev = None if edge_values is None else np.ascontiguousarray(edge_values, dtype=np.int32)
+        h = C.c_void_p()
+        _check(lib().grx_graph_from_csr(nodes, ci.shape[0], _p(ro), _p(ci), None if ev is None else _p(ev),
+                                        C.byref(h)), "grx_graph_from_csr")
+        return cls(h.value)
+
+    @property
+    def row_offsets(self):
+        return np.ctypeslib.as_array(lib().grx_graph_row_offsets(self._h), shape=(self.nodes + 1,))
+
+    @property
+    def col_indices(self):
+        if self.edges == 0:
+            return np.empty(0, dtype=np.int32)
+        return np.ctypeslib.as_array(lib().grx_graph_col_indices(self._h), shape=(self.edges,))
+
+    @property
+    def edge_values(self):
+        p = lib().grx_graph_edge_values(self._h)
+        if not p or self.edges == 0:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.edges,))
+
+    def highest_degree_node(self):
+        md = C.c_int32()
+        v = lib().grx_graph_highest_degree_node(self._h, C.byref(md))
+        return int(v), int(md.value)
+
+    def average_degree(self):
+        return int(lib().grx_graph_average_degree(self._h))
+
+    def close(self):
+        if self._h:
+            lib().grx_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BfsProblem:
+    """BFSProblem + BFSEnactor behind the handle C ABI (Init once, Reset + Enact per run, Extract)."""
+
+    def __init__(self, mark_pred=False, idempotence=False, instrument=False, device=0):
+        self._h = C.c_void_p()
+        self.mark_pred = bool(mark_pred)
+        _check(lib().grx_bfs_create(C.byref(self._h), int(mark_pred), int(idempotence), int(instrument), device),
+               "grx_bfs_create")
+        self.nodes = 0
+
+    def init(self, nodes, row_offsets, col_indices):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        self.nodes = int(nodes)
+        _check(lib().grx_bfs_init(self._h, nodes, ci.shape[0], _p(ro), _p(ci)), "BFSProblem::Init")
+        return self
+
+    def init_device(self, nodes, edges, d_row_offsets, d_col_indices):
+        """d_* are integer device addresses (e.g. torch.Tensor.data_ptr()); borrowed, must outlive the problem."""
+        self.nodes = int(nodes)
+        _check(lib().grx_bfs_init_device(self._h, nodes, edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices)),
+               "BFSProblem::Init(device)")
+        return self
+
+    def reset(self, src, queue_sizing=1.0):
+        _check(lib().grx_bfs_reset(self._h, int(src), float(queue_sizing)), "BFSProblem::Reset")
+
+    def enact(self, src, max_grid_size=0, traversal_mode=0):
+        ms = C.c_float()
+        _check(lib().grx_bfs_enact(self._h, int(src), max_grid_size, traversal_mode, C.byref(ms)), "BFSEnactor::Enact")
+        return float(ms.value)
+
+    def stats(self):
+        q, d, l = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        duty, kms = C.c_double(), C.c_double()
+        _check(lib().grx_bfs_stats(self._h, C.byref(q), C.byref(d), C.byref(duty), C.byref(l), C.byref(kms)),
+               "BFSEnactor::GetStatistics")
+        return {"total_queued": q.value, "search_depth": d.value, "avg_duty": duty.value,
+                "kernel_launches": l.value, "kernel_ms": kms.value}
+
+    def extract(self):
+        labels = np.empty(max(self.nodes, 1), dtype=np.int32)
+        preds = np.empty(max(self.nodes, 1), dtype=np.int32) if self.mark_pred else None
+        _check(lib().grx_bfs_extract(self._h, _p(labels), None if preds is None else _p(preds)), "BFSProblem::Extract")
+        return labels[:self.nodes], (None if preds is None else preds[:self.nodes])
+
+    def device_results(self):
+        dl, dp = C.c_void_p(), C.c_void_p()
+        _check(lib().grx_bfs_device_results(self._h, C.byref(dl), C.byref(dp)), "grx_bfs_device_results")
+        return dl.value, dp.value
+
+    def close(self):
+        if self._h:
+            lib().grx_bfs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _graph_struct(nodes, row_offsets, col_indices, edge_values=None):
+    g = GunrockGraph()
+    g.num_nodes = nodes
+    g.num_edges = col_indices.shape[0]
+    g.row_offsets = row_offsets.ctypes.data
+    g.col_indices = col_indices.ctypes.data
+    g.edge_values = None if edge_values is None else edge_values.ctypes.data
+    return g
+
+
+def _take_node_values(gout, nodes, dtype):
+    """graph_out->node_values is malloc()ed by the library and owned by the caller (bfs_app.cu:211)."""
+    ptr = gout.node_values
+    if not ptr:
+        raise RuntimeError("gunrockinst_amd: the call produced no node_values")
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(max(nodes, 1),))[:nodes].copy()
+    C.CDLL(None).free(C.c_void_p(ptr))
+    return arr.view(dtype)
+
+
+def gunrock_bfs(nodes, row_offsets, col_indices, src=0, mark_pred=False, idempotence=False, queue_size=1.0,
+                src_mode=SRC_MANUALLY, device=0):
+    """Call gunrock_bfs_func exactly as reference shared_lib_tests/test_bfs.c does; returns the labels."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    gin = _graph_struct(nodes, ro, ci)
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.mark_pred, cfg.idempotence = mark_pred, idempotence
+    cfg.src_node, cfg.device, cfg.queue_size, cfg.src_mode = src, device, queue_size, src_mode
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
+    lib().gunrock_bfs_func(C.byref(gout), C.byref(gin), cfg, dt)
+    return _take_node_values(gout, nodes, np.int32)

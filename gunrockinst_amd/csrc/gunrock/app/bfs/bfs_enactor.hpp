@@ -1,0 +1,133 @@
+// app/bfs/bfs_enactor.hpp -- host BSP loop for breadth-first search.
+//
+// Public contract of the reference's BFSEnactor (gunrock/app/bfs/bfs_enactor.cuh:40-708):
+//   template <bool INSTRUMENT> class BFSEnactor : EnactorBase
+//   Enact<BFSProblem>(context, problem, src, max_grid_size = 0, traversal_mode = 0)   (:573-579)
+//   GetStatistics(total_queued, search_depth, avg_duty)                               (:173-186)
+// The reference loop runs advance + filter per level with three blocking 4-byte D2H reads, an event
+// sync, 5-6 launches and 2 moderngpu calls (bfs_enactor.cuh:267-531), and cudaMallocs an
+// E*4-byte scan buffer inside every timed Enact (:254-259).  Here one level = ONE kernel launch (the
+// advance discovers, labels and enqueues; its FrontierWriter emits the next level's degree prefix) and
+// ONE 8-byte read of the packed tail, which tells the host both the next frontier length and its edge
+// count.  No allocation happens inside Enact.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <gunrock/app/bfs/bfs_functor.hpp>
+#include <gunrock/app/bfs/bfs_problem.hpp>
+#include <gunrock/app/enactor_base.hpp>
+#include <gunrock/oprtr/advance/kernel.hpp>
+#include <gunrock/util/context.hpp>
+
+namespace gunrock {
+namespace app {
+namespace bfs {
+
+template <bool INSTRUMENT>
+class BFSEnactor : public EnactorBase {
+   public:
+    explicit BFSEnactor(bool DEBUG = false) : EnactorBase(VERTEX_FRONTIERS, DEBUG) {}
+    ~BFSEnactor() override {}
+
+    // INSTRUMENT extras: operator launches and their summed device time in the last Enact
+    void GetKernelStatistics(long long &launches, double &kernel_ms)
+    {
+        launches = enactor_stats.kernel_launches;
+        kernel_ms = enactor_stats.kernel_ms;
+    }
+
+    void GetStatistics(long long &total_queued, long long &search_depth, double &avg_duty)
+    {
+        total_queued = enactor_stats.total_queued;
+        search_depth = enactor_stats.iteration;
+        avg_duty = (enactor_stats.total_lifetimes > 0) ? enactor_stats.total_runtimes / enactor_stats.total_lifetimes : 0.0;
+    }
+    template <typename T>
+    void GetStatistics(long long &total_queued, T &search_depth, double &avg_duty)
+    {
+        long long depth;
+        GetStatistics(total_queued, depth, avg_duty);
+        search_depth = static_cast<T>(depth);
+    }
+
+    // Load-balanced advance policy: 256 threads x 8 slots = 2048 edge slots per tile, 37 KB LDS,
+    // 4 workgroups (16 waves) per CU.
+    typedef oprtr::advance::KernelPolicy<256, 8, 4, oprtr::advance::LB> LBAdvancePolicy;
+
+    template <typename BFSProblem>
+    hipError_t Enact(util::DeviceContext & /*context*/, BFSProblem *problem, typename BFSProblem::VertexId src,
+                     int max_grid_size = 0, int /*traversal_mode*/ = 0)
+    {
+        return EnactBFS<LBAdvancePolicy, BFSProblem>(problem, src, max_grid_size);
+    }
+
+   protected:
+    template <typename AdvancePolicy, typename BFSProblem>
+    hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size)
+    {
+        typedef typename BFSProblem::VertexId VertexId;
+        typedef typename BFSProblem::SizeT SizeT;
+        typedef typename BFSProblem::Value Value;
+        typedef BFSFunctor<VertexId, SizeT, Value, BFSProblem> BfsFunctor;
+
+        hipError_t retval = hipSuccess;
+        if ((retval = EnactorBase::Setup(max_grid_size, AdvancePolicy::MIN_BLOCKS, 8))) return retval;
+
+        GraphSlice<VertexId, SizeT, Value> *gs = problem->graph_slices[0];
+        typename BFSProblem::DataSlice *ds = problem->data_slices[0];
+        hipStream_t stream = gs->stream;
+        if (src < 0 || src >= problem->nodes) return retval;
+
+        if ((retval = work_progress.Reset(stream))) return retval;
+        unsigned queue_length = problem->SourceDegree() > 0 ? 1u : 0u;
+        unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
+        if ((retval = work_progress.SetTail(0, queue_length, queue_edges, stream))) return retval;
+
+        int selector = 0;
+        long long iteration = 0;
+        while (queue_length > 0) {
+            enactor_stats.total_queued += queue_length;
+            enactor_stats.total_edges_queued += queue_edges;
+
+            oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
+            args.in = gs->frontier_queues[selector];
+            args.out = gs->frontier_queues[selector ^ 1];
+            args.in_len = static_cast<SizeT>(queue_length);
+            args.in_edges = static_cast<SizeT>(queue_edges);
+            args.d_row_offsets = gs->d_row_offsets;
+            args.d_column_indices = gs->d_column_indices;
+            args.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
+            args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
+            args.d_overflow = work_progress.d_overflow;
+            ds->iteration = static_cast<VertexId>(iteration);
+
+            if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
+            if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
+                     args, *ds, enactor_stats.advance_grid_size, stream, oprtr::advance::V2V)))
+                break;
+            if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
+
+            ++iteration;
+            selector ^= 1;
+            if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+            if (INSTRUMENT) InstrumentCollect();
+            if (DEBUG) std::printf("iteration %lld: queue length %u, edges %u\n", iteration, queue_length, queue_edges);
+        }
+        enactor_stats.iteration = iteration;
+        if (retval) return retval;
+
+        bool overflow = false;
+        if ((retval = work_progress.CheckOverflow(overflow, stream))) return retval;
+        if (overflow) {
+            // same diagnosis as bfs_enactor.cuh:540-545
+            retval = util::GRError(hipErrorInvalidConfiguration,
+                                   "Frontier queue overflow. Please increase queue-sizing factor.", __FILE__, __LINE__);
+        }
+        return retval;
+    }
+};
+
+}  // namespace bfs
+}  // namespace app
+}  // namespace gunrock

@@ -1,0 +1,61 @@
+// app/bfs/bfs_functor.hpp -- BFS functor for the advance / filter operators.
+//
+// Signature and role identical to the reference's BFSFunctor (gunrock/app/bfs/bfs_functor.cuh:33-122):
+//   CondEdge(s_id, d_id, problem, e_id, e_id_in)  -> does this edge discover d_id?
+//   ApplyEdge(...)                                 -> record the discovery
+//   CondFilter(node, problem, v, nid)              -> keep `node` in the compacted frontier?
+//   ApplyFilter(...)
+// Reference semantics: non-idempotent modes claim the vertex with atomicCAS on
+// labels/preds (bfs_functor.cuh:56-58); idempotent mode accepts every edge and lets the filter cull
+// (bfs_functor.cuh:51-52, filter/cta.cuh:166-253).  All of them end with label = BFS depth.
+//
+// Here one rule serves all four modes: test-and-set the destination's bit in the L2-resident visited
+// bitmap.  A relaxed plain load screens out already-visited destinations (the common case on the big
+// R-MAT levels); only survivors pay the agent-scope atomicOr, whose return value elects exactly one
+// discoverer.  The winner writes label = iteration + 1 (the value the reference passes as
+// `label`/`iteration+1`, edge_map_partitioned/kernel.cuh:401-403, bfs_enactor.cuh:483) and, when
+// MARK_PREDECESSORS, pred = s_id -- a valid parent because s_id is in the current frontier.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace gunrock {
+namespace app {
+namespace bfs {
+
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct BFSFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+
+    static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
+                                                    VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
+    {
+        unsigned *word = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
+        const unsigned bit = 1u << (d_id & 31);
+        if (*word & bit) return false;                    // stale-tolerant screen
+        return (atomicOr(word, bit) & bit) == 0;          // exactly one winner per vertex
+    }
+
+    static __device__ __forceinline__ void ApplyEdge(VertexId s_id, VertexId d_id, DataSlice *problem,
+                                                     VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
+    {
+        problem->d_labels[d_id] = problem->iteration + 1;
+        if (ProblemData::MARK_PREDECESSORS) problem->d_preds[d_id] = s_id;
+    }
+
+    static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice * /*problem*/, Value /*v*/ = 0,
+                                                      SizeT /*nid*/ = 0)
+    {
+        return node != -1;
+    }
+
+    static __device__ __forceinline__ void ApplyFilter(VertexId /*node*/, DataSlice * /*problem*/, Value /*v*/ = 0,
+                                                       SizeT /*nid*/ = 0)
+    {
+        // labels were written by the unique discoverer in ApplyEdge
+    }
+};
+
+}  // namespace bfs
+}  // namespace app
+}  // namespace gunrock

@@ -1,0 +1,90 @@
+// device_intrinsics.hpp -- wave64 building blocks for gfx950 (CDNA4).
+//
+// Replaces the reference's warp-32 / inline-PTX helpers (gunrock/util/device_intrinsics.cuh:24-92,
+// util/scan/warp_scan.cuh, util/scan/cooperative_scan.cuh:152-173) with native wave64 forms:
+// 64-bit ballots, v_mbcnt lane ranks, shuffle-based wave scans and a workgroup scan that
+// combines wave totals through LDS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace gunrock {
+namespace util {
+
+constexpr int kWaveSize = 64;
+
+__device__ __forceinline__ unsigned LaneId()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Number of set bits of `mask` strictly below the calling lane.
+__device__ __forceinline__ unsigned RankInMask(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave (all lanes must call).
+template <typename T>
+__device__ __forceinline__ T WaveInclusiveSum(T x)
+{
+    const unsigned lane = LaneId();
+#pragma unroll
+    for (int d = 1; d < kWaveSize; d <<= 1) {
+        T y = __shfl_up(x, d, kWaveSize);
+        if (lane >= static_cast<unsigned>(d)) x += y;
+    }
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ T WaveSum(T x)
+{
+#pragma unroll
+    for (int d = kWaveSize / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, kWaveSize);
+    return x;
+}
+
+// Workgroup-wide exclusive prefix sum; every thread of the THREADS-sized block must call.
+// `total` receives the block total in every thread.  Two barriers per call.
+template <int THREADS, typename T>
+struct BlockScan {
+    static constexpr int WAVES = THREADS / kWaveSize;
+    struct Storage {
+        T wave_total[WAVES];
+    };
+
+    static __device__ __forceinline__ T ExclusiveSum(T x, T &total, Storage &st)
+    {
+        const unsigned lane = LaneId();
+        const unsigned wave = threadIdx.x / kWaveSize;
+        T incl = WaveInclusiveSum(x);
+        if (lane == kWaveSize - 1) st.wave_total[wave] = incl;
+        __syncthreads();
+        T base = 0, sum = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            T t = st.wave_total[w];
+            if (static_cast<unsigned>(w) < wave) base += t;
+            sum += t;
+        }
+        __syncthreads();  // storage may be reused right away
+        total = sum;
+        return base + incl - x;
+    }
+};
+
+// Agent-scope relaxed accessors for words other workgroups update inside the same launch
+// (per-XCD L2s are not coherent; plain loads may be served from a stale L1/L2 line).
+__device__ __forceinline__ unsigned LoadAgent(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int LoadAgent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace util
+}  // namespace gunrock

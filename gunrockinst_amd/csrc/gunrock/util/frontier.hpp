@@ -1,0 +1,112 @@
+// frontier.hpp -- device frontier queues and the work-progress counters that go with them.
+//
+// MI355X-first redesign of the reference's ping-pong frontier queues
+// (gunrock/app/problem_base.cuh:73-140 GraphSlice::frontier_queues, util/multiple_buffering.cuh:92-131)
+// and of CtaWorkProgress (gunrock/util/cta_work_progress.cuh:51-360):
+//
+//  * A frontier is three parallel arrays: vertex id, the vertex's first edge (row start) and the
+//    EXCLUSIVE prefix sum of degrees in queue order.  The prefix is produced by whoever WRITES the
+//    frontier (FrontierWriter in oprtr/frontier_writer.hpp) from one packed 64-bit reservation per
+//    flushed batch, so the load-balanced advance needs no separate degree-gather, device-wide scan or
+//    sorted-search pass per BFS level (reference: GetEdgeCounts + mgpu::Scan + MarkPartitionSizes +
+//    mgpu::SortedSearch, oprtr/advance/kernel.cuh:300-368) and no blocking 4-byte length read inside
+//    the operator (advance/kernel.cuh:315-317).
+//  * One packed counter per BSP step: low 32 bits = queued vertices, high 32 bits = queued edges.
+//    Counters form a ring of 4 like the reference's queue-length slots; the kernel of step k writes
+//    slot (k+1)&3 and clears slot (k+2)&3 (cta_work_progress.cuh:55-72 protocol).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include <gunrock/util/error_utils.hpp>
+
+namespace gunrock {
+namespace util {
+
+template <typename VertexId, typename SizeT>
+struct Frontier {
+    VertexId *v = nullptr;   // vertex ids
+    SizeT *row_start = nullptr;  // first edge of each vertex (offset into column_indices)
+    SizeT *scan = nullptr;   // exclusive prefix sum of degrees, in queue order
+    SizeT capacity = 0;
+};
+
+__host__ __device__ __forceinline__ unsigned long long PackTail(unsigned count, unsigned edges)
+{
+    return (static_cast<unsigned long long>(edges) << 32) | count;
+}
+__host__ __device__ __forceinline__ unsigned TailCount(unsigned long long t) { return static_cast<unsigned>(t); }
+__host__ __device__ __forceinline__ unsigned TailEdges(unsigned long long t) { return static_cast<unsigned>(t >> 32); }
+
+// Device words shared by all kernels of one enactor.
+struct WorkProgress {
+    static constexpr int kSlots = 4;
+    unsigned long long *d_tail = nullptr;  // [kSlots] packed (edges<<32 | vertices)
+    int *d_overflow = nullptr;             // set when a writer ran out of queue capacity
+    unsigned long long *h_tail = nullptr;  // pinned mirror for the per-step read-back
+    int *h_overflow = nullptr;
+
+    hipError_t Init()
+    {
+        hipError_t retval = hipSuccess;
+        if (d_tail) return retval;
+        GR_CHECK(hipMalloc(&d_tail, sizeof(unsigned long long) * kSlots), "WorkProgress hipMalloc d_tail failed");
+        GR_CHECK(hipMalloc(&d_overflow, sizeof(int)), "WorkProgress hipMalloc d_overflow failed");
+        GR_CHECK(hipHostMalloc(&h_tail, sizeof(unsigned long long) * kSlots, hipHostMallocDefault),
+                 "WorkProgress hipHostMalloc failed");
+        GR_CHECK(hipHostMalloc(&h_overflow, sizeof(int), hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
+        return Reset(0);
+    }
+
+    hipError_t Reset(hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemsetAsync(d_tail, 0, sizeof(unsigned long long) * kSlots, stream), "WorkProgress memset failed");
+        GR_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(int), stream), "WorkProgress memset failed");
+        return retval;
+    }
+
+    hipError_t SetTail(int slot, unsigned count, unsigned edges, hipStream_t stream)
+    {
+        h_tail[slot & 3] = PackTail(count, edges);
+        return GRError(hipMemcpyAsync(d_tail + (slot & 3), h_tail + (slot & 3), sizeof(unsigned long long),
+                                      hipMemcpyHostToDevice, stream),
+                       "WorkProgress SetTail failed", __FILE__, __LINE__);
+    }
+
+    // Blocking read of one slot (the only host<->device sync of a BSP step).
+    hipError_t GetTail(int slot, unsigned &count, unsigned &edges, hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemcpyAsync(h_tail + (slot & 3), d_tail + (slot & 3), sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, stream),
+                 "WorkProgress GetTail copy failed");
+        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetTail sync failed");
+        count = TailCount(h_tail[slot & 3]);
+        edges = TailEdges(h_tail[slot & 3]);
+        return retval;
+    }
+
+    hipError_t CheckOverflow(bool &overflow, hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost, stream),
+                 "WorkProgress CheckOverflow copy failed");
+        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress CheckOverflow sync failed");
+        overflow = (*h_overflow != 0);
+        return retval;
+    }
+
+    void Release()
+    {
+        if (d_tail) GRError(hipFree(d_tail), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        if (d_overflow) GRError(hipFree(d_overflow), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        if (h_tail) GRError(hipHostFree(h_tail), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        if (h_overflow) GRError(hipHostFree(h_overflow), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        d_tail = nullptr; d_overflow = nullptr; h_tail = nullptr; h_overflow = nullptr;
+    }
+};
+
+}  // namespace util
+}  // namespace gunrock

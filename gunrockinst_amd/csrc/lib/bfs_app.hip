@@ -1,0 +1,257 @@
+// lib/bfs_app.hip -- BFS entry points of libgunrock.so.
+//
+//  * gunrock_bfs_func: drop-in for the reference's C entry point (gunrock/app/bfs/bfs_app.cu:383-396
+//    -> dispatch_bfs :241-366 -> run_bfs :146-230), same source-selection rules (:271-294), same
+//    ownership rules (caller's CSR borrowed, labels malloc()ed for the caller, :165,211,256-260,350-351),
+//    same stdout statistics block (:103-118).
+//  * grx_bfs_*: the Problem / Enactor phases as separate C calls (include/gunrock/gunrock_mi355x.h).
+#include <gunrock/gunrock.h>
+#include <gunrock/gunrock_mi355x.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include <gunrock/app/bfs/bfs_enactor.hpp>
+#include <gunrock/app/bfs/bfs_problem.hpp>
+#include <gunrock/csr.hpp>
+#include <gunrock/graphio/utils.hpp>
+#include <gunrock/util/context.hpp>
+
+using namespace gunrock;
+using namespace gunrock::app;
+using namespace gunrock::app::bfs;
+
+namespace {
+
+// Type-erased holder so one C handle serves the four <MARK_PREDECESSORS, ENABLE_IDEMPOTENCE> instantiations
+// (reference bfs_app.cu:299-348 picks them with nested ifs).
+struct BfsRunner {
+    virtual ~BfsRunner() {}
+    virtual hipError_t Init(const Csr<int, int, int> &g) = 0;
+    virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
+    virtual hipError_t Reset(int src, double queue_sizing) = 0;
+    virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
+    virtual void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) = 0;
+    virtual hipError_t Extract(int *labels, int *preds) = 0;
+    virtual void DeviceResults(int **labels, int **preds) = 0;
+};
+
+template <bool PRED, bool IDEMP, bool INSTR>
+struct BfsRunnerT : BfsRunner {
+    typedef BFSProblem<int, int, int, PRED, IDEMP, (PRED && IDEMP)> Problem;
+    util::DeviceContext context;
+    Problem problem;
+    BFSEnactor<INSTR> enactor;
+    hipEvent_t start = nullptr, stop = nullptr;
+
+    explicit BfsRunnerT(int device) : context(device), enactor(false)
+    {
+        util::GRError(hipEventCreate(&start), "hipEventCreate failed", __FILE__, __LINE__);
+        util::GRError(hipEventCreate(&stop), "hipEventCreate failed", __FILE__, __LINE__);
+    }
+    ~BfsRunnerT() override
+    {
+        if (start) hipEventDestroy(start);
+        if (stop) hipEventDestroy(stop);
+    }
+    hipError_t Init(const Csr<int, int, int> &g) override { return problem.Init(false, g, 1); }
+    hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) override
+    {
+        return problem.InitFromDevice(nodes, edges, d_ro, d_ci);
+    }
+    hipError_t Reset(int src, double queue_sizing) override
+    {
+        return problem.Reset(src, enactor.GetFrontierType(), queue_sizing);
+    }
+    hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) override
+    {
+        hipStream_t stream = problem.graph_slices[0]->stream;
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipEventRecord(start, stream), "hipEventRecord failed");
+        hipError_t run = enactor.template Enact<Problem>(context, &problem, src, max_grid_size, traversal_mode);
+        GR_CHECK(hipEventRecord(stop, stream), "hipEventRecord failed");
+        GR_CHECK(hipEventSynchronize(stop), "hipEventSynchronize failed");
+        float t = 0;
+        GR_CHECK(hipEventElapsedTime(&t, start, stop), "hipEventElapsedTime failed");
+        if (ms) *ms = t;
+        return run;
+    }
+    void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) override
+    {
+        enactor.GetStatistics(queued, depth, duty);
+        enactor.GetKernelStatistics(launches, kernel_ms);
+    }
+    hipError_t Extract(int *labels, int *preds) override { return problem.Extract(labels, preds); }
+    void DeviceResults(int **labels, int **preds) override
+    {
+        if (labels) *labels = problem.data_slices ? problem.data_slices[0]->d_labels : nullptr;
+        if (preds) *preds = problem.data_slices ? problem.data_slices[0]->d_preds : nullptr;
+    }
+};
+
+BfsRunner *MakeRunner(bool pred, bool idemp, bool instr, int device)
+{
+    if (instr) {
+        if (pred) return idemp ? static_cast<BfsRunner *>(new BfsRunnerT<true, true, true>(device))
+                               : new BfsRunnerT<true, false, true>(device);
+        return idemp ? static_cast<BfsRunner *>(new BfsRunnerT<false, true, true>(device))
+                     : new BfsRunnerT<false, false, true>(device);
+    }
+    if (pred) return idemp ? static_cast<BfsRunner *>(new BfsRunnerT<true, true, false>(device))
+                           : new BfsRunnerT<true, false, false>(device);
+    return idemp ? static_cast<BfsRunner *>(new BfsRunnerT<false, true, false>(device))
+                 : new BfsRunnerT<false, false, false>(device);
+}
+
+// stdout block of the reference's DisplayStats (bfs_app.cu:76-118)
+void DisplayStats(const char *name, int src, const int *h_labels, const Csr<int, int, int> &graph, double elapsed,
+                  long long search_depth, long long total_queued, double avg_duty)
+{
+    long long nodes_visited = 0, edges_visited = 0;
+    grx_bfs_count_visited(graph.nodes, graph.row_offsets, h_labels, &nodes_visited, &edges_visited);
+    double redundant_work = 0.0;
+    if (total_queued > 0 && edges_visited > 0)
+        redundant_work = 100.0 * (static_cast<double>(total_queued) - edges_visited) / edges_visited;
+    std::printf("[%s] finished.", name);
+    if (nodes_visited < 5) {
+        std::printf("Fewer than 5 vertices visited.\n");
+        return;
+    }
+    const double m_teps = static_cast<double>(edges_visited) / (elapsed * 1000.0);
+    std::printf("\nelapsed: %.3f ms, rate: %.3f MiEdges/s", elapsed, m_teps);
+    if (search_depth != 0) std::printf(", search_depth: %lld", search_depth);
+    if (avg_duty != 0) std::printf("\n avg CTA duty: %.2f%%", avg_duty * 100);
+    std::printf("\nsource_node: %lld, nodes_visited: %lld, edges visited: %lld", static_cast<long long>(src),
+                nodes_visited, edges_visited);
+    if (total_queued > 0) std::printf(", total queued: %lld", total_queued);
+    if (redundant_work > 0) std::printf(", redundant work: %.2f%%", redundant_work);
+    std::printf("\n");
+}
+
+}  // namespace
+
+struct grx_bfs {
+    BfsRunner *runner = nullptr;
+};
+
+extern "C" {
+
+int grx_bfs_create(grx_bfs **out, int mark_pred, int idempotence, int instrument, int device)
+{
+    if (!out) return -1;
+    grx_bfs *h = new grx_bfs();
+    h->runner = MakeRunner(mark_pred != 0, idempotence != 0, instrument != 0, device);
+    *out = h;
+    return 0;
+}
+
+int grx_bfs_init(grx_bfs *p, int nodes, int edges, const int *row_offsets, const int *col_indices)
+{
+    if (!p || !row_offsets || nodes < 0 || edges < 0) return -1;
+    Csr<int, int, int> wrap(false);  // borrow the caller's arrays (bfs_app.cu:256-260)
+    wrap.nodes = nodes;
+    wrap.edges = edges;
+    wrap.row_offsets = const_cast<int *>(row_offsets);
+    wrap.column_indices = const_cast<int *>(col_indices);
+    hipError_t rc = p->runner->Init(wrap);
+    wrap.row_offsets = nullptr;  // do not free what we do not own (bfs_app.cu:350-351)
+    wrap.column_indices = nullptr;
+    return static_cast<int>(rc);
+}
+
+int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices)
+{
+    if (!p || !d_row_offsets || nodes < 0 || edges < 0) return -1;
+    return static_cast<int>(p->runner->InitDevice(nodes, edges, d_row_offsets, d_col_indices));
+}
+
+int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing)
+{
+    if (!p) return -1;
+    return static_cast<int>(p->runner->Reset(src, queue_sizing));
+}
+
+int grx_bfs_enact(grx_bfs *p, int src, int max_grid_size, int traversal_mode, float *elapsed_ms)
+{
+    if (!p) return -1;
+    return static_cast<int>(p->runner->Enact(src, max_grid_size, traversal_mode, elapsed_ms));
+}
+
+int grx_bfs_stats(grx_bfs *p, long long *total_queued, long long *search_depth, double *avg_duty,
+                  long long *kernel_launches, double *kernel_ms)
+{
+    if (!p) return -1;
+    long long q = 0, d = 0, l = 0;
+    double duty = 0, kms = 0;
+    p->runner->Stats(q, d, duty, l, kms);
+    if (total_queued) *total_queued = q;
+    if (search_depth) *search_depth = d;
+    if (avg_duty) *avg_duty = duty;
+    if (kernel_launches) *kernel_launches = l;
+    if (kernel_ms) *kernel_ms = kms;
+    return 0;
+}
+
+int grx_bfs_extract(grx_bfs *p, int *h_labels, int *h_preds)
+{
+    if (!p || !h_labels) return -1;
+    return static_cast<int>(p->runner->Extract(h_labels, h_preds));
+}
+
+int grx_bfs_device_results(grx_bfs *p, int **d_labels, int **d_preds)
+{
+    if (!p) return -1;
+    p->runner->DeviceResults(d_labels, d_preds);
+    return 0;
+}
+
+void grx_bfs_destroy(grx_bfs *p)
+{
+    if (!p) return;
+    delete p->runner;
+    delete p;
+}
+
+void gunrock_bfs_func(struct GunrockGraph *graph_out, const struct GunrockGraph *graph_in, struct GunrockConfig configs,
+                      struct GunrockDataType data_type)
+{
+    if (!graph_out || !graph_in) return;
+    if (data_type.VTXID_TYPE != VTXID_INT || data_type.SIZET_TYPE != SIZET_INT) return;
+    if (data_type.VALUE_TYPE != VALUE_INT) {
+        std::printf("Not Yet Support This DataType Combination.\n");  // bfs_app.cu:354-365
+        return;
+    }
+    Csr<int, int, int> csr(false);
+    csr.nodes = static_cast<int>(graph_in->num_nodes);
+    csr.edges = static_cast<int>(graph_in->num_edges);
+    csr.row_offsets = static_cast<int *>(graph_in->row_offsets);
+    csr.column_indices = static_cast<int *>(graph_in->col_indices);
+
+    int src = 0;
+    switch (configs.src_mode) {  // bfs_app.cu:271-294
+        case randomize: src = graphio::RandomNode(csr.nodes); break;
+        case largest_degree: { int md = 0; src = csr.GetNodeWithHighestDegree(md); break; }
+        case manually: src = configs.src_node; break;
+        default: src = 0; break;
+    }
+    const double queue_sizing = configs.queue_size > 0 ? configs.queue_size : 1.0;
+
+    int *h_labels = static_cast<int *>(std::malloc(sizeof(int) * static_cast<size_t>(csr.nodes > 0 ? csr.nodes : 1)));
+    BfsRunner *runner = MakeRunner(configs.mark_pred, configs.idempotence, false, configs.device);
+    float elapsed = 0;
+    hipError_t rc = runner->Init(csr);
+    if (!rc) rc = util::GRError(runner->Reset(src, queue_sizing), "BFS Problem Data Reset Failed", __FILE__, __LINE__);
+    if (!rc) rc = util::GRError(runner->Enact(src, 0, 0, &elapsed), "BFS Problem Enact Failed", __FILE__, __LINE__);
+    long long queued = 0, depth = 0, launches = 0;
+    double duty = 0, kernel_ms = 0;
+    runner->Stats(queued, depth, duty, launches, kernel_ms);
+    if (!rc) rc = util::GRError(runner->Extract(h_labels, nullptr), "BFS Problem Data Extraction Failed", __FILE__, __LINE__);
+    graph_out->node_values = h_labels;  // caller frees (bfs_app.cu:211)
+    if (!rc) DisplayStats("GPU Breadth-first search", src, h_labels, csr, elapsed, depth, queued, duty);
+    delete runner;
+    csr.row_offsets = nullptr;
+    csr.column_indices = nullptr;
+    util::GRError(hipDeviceSynchronize(), "hipDeviceSynchronize failed", __FILE__, __LINE__);
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+/*
+ * gunrock/gunrock_mi355x.h -- handle-based C ABI over the engine's Problem / Enactor classes.
+ *
+ * gunrock.h's one-shot calls (upload, run, download, free) hide the phases the reference's own
+ * drivers time separately (tests/bfs/test_bfs.cu:385-445: Init once, then Reset + timed Enact per
+ * run, Extract, validate).  This header exposes those phases -- and the host graph builders the
+ * drivers use -- as plain C entry points with plain pointers and sizes, so a foreign-language host
+ * (ctypes / cgo / JNI) can keep a graph resident in HBM across runs.  Every function cites the
+ * reference C++ interface it stands for.
+ *
+ * All functions return 0 on success, a positive hipError_t value on a HIP failure (already printed
+ * to stderr in the reference's GRError format) or a negative value for a host-side error.
+ * "d_" pointers are device (HBM) addresses; everything else is host memory.
+ */
+#ifndef GUNROCK_GUNROCK_MI355X_H_
+#define GUNROCK_GUNROCK_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Host graphs: gunrock::Csr<int,int,int> (reference gunrock/csr.cuh:38-80)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct grx_graph grx_graph;
+
+/* graphio::BuildMarketGraph<true>(file, csr, undirected, reversed)  (reference graphio/market.cuh:296-339) */
+int grx_graph_from_market(const char *path, int undirected, int reversed, grx_graph **out);
+/* graphio::BuildRmatGraph<true>(nodes, edges, csr, undirected, a,b,c,d) on libc rand() (reference graphio/rmat.cuh:27-91) */
+int grx_graph_rmat_libc(int nodes, int edges, int undirected, double a, double b, double c, double d, grx_graph **out);
+/* seeded counter-based R-MAT: 2^scale vertices, `pairs` generated edges (mirrored when undirected) */
+int grx_graph_rmat_seeded(int scale, long long pairs, uint64_t seed, int undirected,
+                          double a, double b, double c, double d, grx_graph **out);
+/* Csr::FromCoo<true>(coo, nodes, tuples)  (reference csr.cuh:247-340): stable sort, drop self loops + repeats */
+int grx_graph_from_coo(int nodes, long long tuples, const int *rows, const int *cols, const int *vals, grx_graph **out);
+/* wrap existing CSR arrays (copied) -- what bfs_app.cu:256-260 does with the caller's pointers */
+int grx_graph_from_csr(int nodes, int edges, const int *row_offsets, const int *col_indices, const int *edge_values,
+                       grx_graph **out);
+int grx_graph_nodes(const grx_graph *g);
+int grx_graph_edges(const grx_graph *g);
+const int *grx_graph_row_offsets(const grx_graph *g);
+const int *grx_graph_col_indices(const grx_graph *g);
+const int *grx_graph_edge_values(const grx_graph *g);   /* NULL when the graph carries no values */
+/* Csr::GetNodeWithHighestDegree (reference csr.cuh:442-455) / GetAverageDegree (csr.cuh:475-485) */
+int grx_graph_highest_degree_node(grx_graph *g, int *max_degree);
+int grx_graph_average_degree(grx_graph *g);
+/* graphio::RandomNode (reference graphio/utils.cuh:38-45) */
+int grx_random_node(int num_nodes);
+void grx_graph_free(grx_graph *g);
+
+/* Device-side seeded R-MAT tuple generation (same stream as grx_graph_rmat_seeded): writes `count` tuples
+ * starting at generated-edge index `first` into d_rows / d_cols.  `stream` is a hipStream_t or NULL. */
+int grx_rmat_seeded_device(int scale, long long first, long long count, uint64_t seed,
+                           double a, double b, double c, double d, int *d_rows, int *d_cols, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BFS: BFSProblem + BFSEnactor (reference gunrock/app/bfs/bfs_problem.cuh:41-364, bfs_enactor.cuh:40-708)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct grx_bfs grx_bfs;
+
+/* picks the <MARK_PREDECESSORS, ENABLE_IDEMPOTENCE> instantiation like dispatch_bfs (reference bfs_app.cu:299-348);
+ * `instrument` selects BFSEnactor<true>: per-launch HIP-event timing of the operator kernels */
+int grx_bfs_create(grx_bfs **out, int mark_pred, int idempotence, int instrument, int device);
+/* BFSProblem::Init(false, csr, 1) (reference bfs_problem.cuh:188-261): uploads the CSR */
+int grx_bfs_init(grx_bfs *p, int nodes, int edges, const int *row_offsets, const int *col_indices);
+/* same, for a CSR that already lives in HBM (pointers are borrowed for the life of the handle) */
+int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices);
+/* BFSProblem::Reset(src, frontier_type, queue_sizing) (reference bfs_problem.cuh:272-360) */
+int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing);
+/* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579),
+ * bracketed by HIP events on the problem's stream like the reference's GpuTimer (test_bfs.cu:408-438) */
+int grx_bfs_enact(grx_bfs *p, int src, int max_grid_size, int traversal_mode, float *elapsed_ms);
+/* BFSEnactor::GetStatistics (reference bfs_enactor.cuh:173-186) plus, when instrumented, operator-kernel
+ * launch count and summed kernel time of the last Enact */
+int grx_bfs_stats(grx_bfs *p, long long *total_queued, long long *search_depth, double *avg_duty,
+                  long long *kernel_launches, double *kernel_ms);
+/* BFSProblem::Extract(h_labels, h_preds) (reference bfs_problem.cuh:144-177); h_preds may be NULL */
+int grx_bfs_extract(grx_bfs *p, int *h_labels, int *h_preds);
+/* device result arrays (valid until destroy / next init) */
+int grx_bfs_device_results(grx_bfs *p, int **d_labels, int **d_preds);
+void grx_bfs_destroy(grx_bfs *p);
+
+/* DisplayStats' counters (reference tests/bfs/test_bfs.cu:184-196): visited vertices and the sum of their
+ * out-degrees -- the numerator of MTEPS = edges_visited / (elapsed_ms * 1000) */
+void grx_bfs_count_visited(int nodes, const int *row_offsets, const int *labels,
+                           long long *nodes_visited, long long *edges_visited);
+
+/* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */
+const char *grx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUNROCK_GUNROCK_MI355X_H_ */

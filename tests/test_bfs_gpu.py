@@ -1,0 +1,143 @@
+"""BFS parity on the GPU: the HIP engine (through the C ABI) against the CPU oracle, bit-exact on labels;
+predecessors are checked as "valid parent" (reference tests/sssp/test_sssp.cu:488-489: paths are not unique)."""
+import os
+
+import numpy as np
+import pytest
+
+import gunrockinst_amd as ga
+from oracle import gr_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(False, False), (True, False), (False, True), (True, True)]
+
+
+def _run(g, src, mark_pred, idempotence, instrument=False, queue_sizing=1.0):
+    p = ga.BfsProblem(mark_pred, idempotence, instrument).init(g.nodes, g.row_offsets, g.col_indices)
+    p.reset(src, queue_sizing)
+    ms = p.enact(src)
+    labels, preds = p.extract()
+    st = p.stats()
+    p.close()
+    return labels, preds, st, ms
+
+
+def _check(g, src, labels, preds, st):
+    ref, _, depth = o.bfs(g, src)
+    assert np.array_equal(labels, ref)
+    if preds is not None:
+        assert o.check_bfs_preds(g, src, labels, preds) == 0
+    # enactor depth = completed iterations; CPU prints max_label + 1
+    assert st["search_depth"] in (depth - 1, depth)
+
+
+@pytest.mark.parametrize("mark_pred,idempotence", MODES)
+def test_fixture7_all_modes(golden, mark_pred, idempotence):
+    f = golden["fixture7"]
+    g = o.Csr(7, f["row_offsets"], f["col_indices"])
+    for src in range(7):
+        labels, preds, st, _ = _run(g, src, mark_pred, idempotence)
+        _check(g, src, labels, preds, st)
+    labels, _, _, _ = _run(g, 0, mark_pred, idempotence)
+    assert labels.tolist() == f["bfs_src0_labels"]
+
+
+def test_c_abi_entry_point_known_answer(golden, capfd):
+    f = golden["fixture7"]
+    ro = np.array(f["row_offsets"], np.int32)
+    ci = np.array(f["col_indices"], np.int32)
+    # reference ctest regex: Node_ID [2] : Label [1] (CMakeLists.txt:215-217) holds for src 0 and src 1
+    labels = ga.gunrock_bfs(7, ro, ci, src=0)
+    assert labels.tolist() == f["bfs_src0_labels"] and labels[2] == 1
+    labels = ga.gunrock_bfs(7, ro, ci, src_mode=ga.SRC_LARGEST_DEGREE, idempotence=True)
+    assert labels.tolist() == f["bfs_src0_labels"]          # first max-degree vertex is 0
+    out = capfd.readouterr().out
+    assert "[GPU Breadth-first search] finished." in out and "MiEdges/s" in out
+
+
+@pytest.mark.parametrize("mark_pred,idempotence", MODES)
+def test_bips98_606_simple_example_path(golden, golden_dir, mark_pred, idempotence):
+    f = golden["bips98_606"]
+    g = o.build_market(os.path.join(golden_dir, f["mtx"]), undirected=True)
+    for src, key in [(0, "bfs_src0"), (566, "bfs_src566")]:
+        labels, preds, st, _ = _run(g, src, mark_pred, idempotence)
+        _check(g, src, labels, preds, st)
+        assert labels[:10].tolist() == f[key]["labels_head"]
+    nv, ev = o.bfs_stats(g, _run(g, 0, mark_pred, idempotence)[0])
+    assert (nv, ev) == (f["bfs_src0"]["nodes_visited"], f["bfs_src0"]["edges_visited"])
+
+
+def test_edge_cases():
+    # isolated source, single vertex, source with only a self-loop-free empty row, chain, star
+    g = o.Csr(4, [0, 0, 1, 1, 1], [0])
+    for src in range(4):
+        labels, preds, st, _ = _run(g, src, True, False)
+        _check(g, src, labels, preds, st)
+    g = o.Csr(1, [0, 0], [])
+    labels, _, st, _ = _run(g, 0, False, True)
+    assert labels.tolist() == [0] and st["search_depth"] == 0
+    n = 5000                                             # long path: many tiny levels
+    ro = np.minimum(np.arange(n + 1), n - 1).astype(np.int32)
+    ci = np.arange(1, n, dtype=np.int32)
+    g = o.Csr(n, ro, ci)
+    labels, preds, st, _ = _run(g, 0, True, True)
+    _check(g, 0, labels, preds, st)
+    assert labels[-1] == n - 1
+    hub = 70000                                          # one row far larger than a tile, split over workgroups
+    ro = np.concatenate(([0], np.full(hub, hub - 1))).astype(np.int32)
+    ro[-1] = hub - 1
+    g = o.Csr(hub, np.concatenate(([0], np.full(hub, hub - 1, dtype=np.int32))), np.arange(1, hub, dtype=np.int32))
+    labels, preds, st, _ = _run(g, 0, True, False)
+    _check(g, 0, labels, preds, st)
+
+
+@pytest.mark.parametrize("scale,ef", [(10, 8), (14, 8), (16, 16), (18, 8)])
+def test_rmat_seeded_parity(scale, ef):
+    g = o.rmat_seeded(scale, ef << scale)
+    src, _ = o.highest_degree_node(g)
+    rng = np.random.default_rng(scale)
+    deg = np.diff(g.row_offsets)
+    others = rng.choice(np.nonzero(deg > 0)[0], 3)
+    for s in [src] + others.tolist():
+        for mark_pred, idempotence in [(False, True), (True, False)]:
+            labels, preds, st, _ = _run(g, int(s), mark_pred, idempotence)
+            _check(g, int(s), labels, preds, st)
+
+
+def test_degree_one_rows_fill_a_tile_exactly():
+    # perfect matching chained: every frontier vertex has degree 1 -> exercises the cursor hand-over rule
+    n = 3 * 2048 + 5
+    ro = np.arange(n + 1, dtype=np.int32)
+    ro[-1] = n - 1
+    ro = np.minimum(ro, n - 1)
+    # layered graph: layer 0 = {0}, vertex 0 -> 1..4100 (wide), each of those -> one private vertex
+    width = 4100
+    rows = [np.zeros(width, np.int32), np.arange(1, width + 1, dtype=np.int32)]
+    cols = [np.arange(1, width + 1, dtype=np.int32), np.arange(width + 1, 2 * width + 1, dtype=np.int32)]
+    g0 = ga.HostGraph.from_coo(2 * width + 1, np.concatenate(rows), np.concatenate(cols))
+    g = o.Csr(g0.nodes, g0.row_offsets.copy(), g0.col_indices.copy())
+    labels, preds, st, _ = _run(g, 0, True, True)
+    _check(g, 0, labels, preds, st)
+    assert (labels[width + 1:] == 2).all()
+
+
+def test_instrumented_run_reports_kernel_time():
+    g = o.rmat_seeded(14, 8 << 14)
+    src, _ = o.highest_degree_node(g)
+    labels, _, st, ms = _run(g, src, False, True, instrument=True)
+    assert np.array_equal(labels, o.bfs(g, src)[0])
+    assert st["kernel_launches"] == st["search_depth"] and 0 < st["kernel_ms"] <= ms
+
+
+def test_reset_and_rerun_same_problem():
+    g = o.rmat_seeded(12, 8 << 12)
+    p = ga.BfsProblem(True, False).init(g.nodes, g.row_offsets, g.col_indices)
+    deg = np.diff(g.row_offsets)
+    for src in np.nonzero(deg > 0)[0][:5].tolist():
+        p.reset(src)
+        p.enact(src)
+        labels, preds = p.extract()
+        assert np.array_equal(labels, o.bfs(g, src)[0])
+        assert o.check_bfs_preds(g, src, labels, preds) == 0
+    p.close()
