@@ -82,10 +82,13 @@ _SIGNATURES = {
     "grx_bfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
     "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "grx_bfs_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                 C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "grx_bfs_level_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_double), i32p]),
     "grx_bfs_extract": (C.c_int, [C.c_void_p, i32p, i32p]),
     "grx_bfs_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "grx_bfs_destroy": (None, [C.c_void_p]),
@@ -238,6 +241,12 @@ class BfsProblem:
                "BFSProblem::Init(device)")
         return self
 
+    def set_inverse_graph(self, d_inv_row_offsets=None, d_inv_col_indices=None, alpha=0.0, beta=0.0):
+        """Enable traversal_mode=2 (direction-optimizing).  No arguments = the graph is symmetric."""
+        _check(lib().grx_bfs_set_inverse_graph(self._h, C.c_void_p(d_inv_row_offsets), C.c_void_p(d_inv_col_indices),
+                                               alpha, beta), "BFSProblem::SetInverseGraph")
+        return self
+
     def reset(self, src, queue_sizing=1.0):
         _check(lib().grx_bfs_reset(self._h, int(src), float(queue_sizing)), "BFSProblem::Reset")
 
@@ -253,6 +262,15 @@ class BfsProblem:
                "BFSEnactor::GetStatistics")
         return {"total_queued": q.value, "search_depth": d.value, "avg_duty": duty.value,
                 "kernel_launches": l.value, "kernel_ms": kms.value}
+
+    def level_trace(self, max_levels=4096):
+        fr = (C.c_longlong * max_levels)()
+        ed = (C.c_longlong * max_levels)()
+        ms = (C.c_double * max_levels)()
+        kd = (C.c_int32 * max_levels)()
+        n = lib().grx_bfs_level_trace(self._h, max_levels, fr, ed, ms, kd)
+        n = min(max(n, 0), max_levels)
+        return [{"frontier": fr[i], "edges": ed[i], "ms": ms[i], "kind": kd[i]} for i in range(n)]
 
     def extract(self):
         labels = np.empty(max(self.nodes, 1), dtype=np.int32)

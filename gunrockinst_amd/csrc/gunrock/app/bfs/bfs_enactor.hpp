@@ -17,6 +17,7 @@
 #include <gunrock/app/bfs/bfs_functor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
 #include <gunrock/app/enactor_base.hpp>
+#include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/oprtr/advance/kernel.hpp>
 #include <gunrock/util/context.hpp>
 
@@ -37,6 +38,8 @@ class BFSEnactor : public EnactorBase {
         kernel_ms = enactor_stats.kernel_ms;
     }
 
+    const std::vector<EnactorStats::LevelRecord> &GetLevelTrace() const { return enactor_stats.levels; }
+
     void GetStatistics(long long &total_queued, long long &search_depth, double &avg_duty)
     {
         total_queued = enactor_stats.total_queued;
@@ -55,21 +58,26 @@ class BFSEnactor : public EnactorBase {
     // 4 workgroups (16 waves) per CU.
     typedef oprtr::advance::KernelPolicy<256, 8, 4, oprtr::advance::LB> LBAdvancePolicy;
 
+    // traversal_mode: 0 = load-balanced top-down advance (reference default, bfs_enactor.cuh:581-697);
+    //                 1 = reserved for the TWC advance (falls back to LB);
+    //                 2 = direction-optimizing (reference app/dobfs): needs BFSProblem::SetInverseGraph.
     template <typename BFSProblem>
     hipError_t Enact(util::DeviceContext & /*context*/, BFSProblem *problem, typename BFSProblem::VertexId src,
-                     int max_grid_size = 0, int /*traversal_mode*/ = 0)
+                     int max_grid_size = 0, int traversal_mode = 0)
     {
-        return EnactBFS<LBAdvancePolicy, BFSProblem>(problem, src, max_grid_size);
+        return EnactBFS<LBAdvancePolicy, BFSProblem>(problem, src, max_grid_size,
+                                                     traversal_mode == 2 && problem->direction_optimizing);
     }
 
    protected:
     template <typename AdvancePolicy, typename BFSProblem>
-    hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size)
+    hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size, bool dobfs)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
         typedef typename BFSProblem::Value Value;
         typedef BFSFunctor<VertexId, SizeT, Value, BFSProblem> BfsFunctor;
+        constexpr int BU_THREADS = 256;
 
         hipError_t retval = hipSuccess;
         if ((retval = EnactorBase::Setup(max_grid_size, AdvancePolicy::MIN_BLOCKS, 8))) return retval;
@@ -84,35 +92,93 @@ class BFSEnactor : public EnactorBase {
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
         if ((retval = work_progress.SetTail(0, queue_length, queue_edges, stream))) return retval;
 
+        const int conv_grid = cu_count * 4;
+        const size_t mask_bytes = sizeof(unsigned) * static_cast<size_t>(problem->MaskWords() + 2);
+        long long unexplored_edges = problem->edges;
+        bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
+        int cur_mask = 0;
         int selector = 0;
         long long iteration = 0;
         while (queue_length > 0) {
             enactor_stats.total_queued += queue_length;
             enactor_stats.total_edges_queued += queue_edges;
+            const unsigned in_len = queue_length, in_edges = queue_edges;
+            if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
 
-            oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
-            args.in = gs->frontier_queues[selector];
-            args.out = gs->frontier_queues[selector ^ 1];
-            args.in_len = static_cast<SizeT>(queue_length);
-            args.in_edges = static_cast<SizeT>(queue_edges);
-            args.d_row_offsets = gs->d_row_offsets;
-            args.d_column_indices = gs->d_column_indices;
-            args.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
-            args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
-            args.d_overflow = work_progress.d_overflow;
+            // ---- direction choice (Beamer's edge rule for down->up, the reference's vertex rule for up->down,
+            //      dobfs_enactor.cuh:397,569) ----
+            if (dobfs && !bottom_up &&
+                static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges)) {
+                // queue -> bitmap
+                if ((retval = util::GRError(hipMemsetAsync(ds->d_frontier_mask[cur_mask], 0, mask_bytes, stream),
+                                            "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
+                    break;
+                hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
+                                   stream, gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length),
+                                   ds->d_frontier_mask[cur_mask]);
+                if ((retval = util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__))) break;
+                bottom_up = true;
+            } else if (dobfs && bottom_up &&
+                       static_cast<double>(queue_length) * problem->beta < static_cast<double>(problem->nodes)) {
+                // bitmap -> queue (exact forward degrees; zero out-degree vertices are dropped)
+                if ((retval = work_progress.ClearAux(stream))) break;
+                hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256),
+                                   0, stream, ds->d_frontier_mask[cur_mask], problem->nodes,
+                                   gs->frontier_queues[selector], work_progress.AuxTail(), work_progress.d_overflow,
+                                   gs->d_row_offsets);
+                if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
+                if ((retval = work_progress.GetAux(queue_length, queue_edges, stream))) break;
+                bottom_up = false;
+                if (queue_length == 0) {  // nothing left that can expand
+                    if (INSTRUMENT) { InstrumentEnd(stream); hipStreamSynchronize(stream); InstrumentCollect(in_len, in_edges, 2); }
+                    break;
+                }
+            }
+            unexplored_edges -= in_edges;
             ds->iteration = static_cast<VertexId>(iteration);
 
-            if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
-            if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
-                     args, *ds, enactor_stats.advance_grid_size, stream, oprtr::advance::V2V)))
-                break;
+            if (bottom_up) {
+                oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
+                bargs.nodes = problem->nodes;
+                bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
+                bargs.d_inv_column_indices = ds->d_inv_column_indices;
+                bargs.d_frontier_in = ds->d_frontier_mask[cur_mask];
+                bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[cur_mask ^ 1]);
+                bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
+                bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
+                bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
+                const long long words = (static_cast<long long>(problem->nodes) + 63) / 64;
+                long long grid = (words + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+                const long long cap = max_grid_size > 0 ? max_grid_size : cu_count * 8;
+                if (grid > cap) grid = cap;
+                if (grid < 1) grid = 1;
+                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem>),
+                                   dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds);
+                if ((retval = util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__))) break;
+                cur_mask ^= 1;
+            } else {
+                oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
+                args.in = gs->frontier_queues[selector];
+                args.out = gs->frontier_queues[selector ^ 1];
+                args.in_len = static_cast<SizeT>(queue_length);
+                args.in_edges = static_cast<SizeT>(queue_edges);
+                args.d_row_offsets = gs->d_row_offsets;
+                args.d_column_indices = gs->d_column_indices;
+                args.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
+                args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
+                args.d_overflow = work_progress.d_overflow;
+                if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
+                         args, *ds, enactor_stats.advance_grid_size, stream, oprtr::advance::V2V)))
+                    break;
+                selector ^= 1;
+            }
             if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
 
             ++iteration;
-            selector ^= 1;
             if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
-            if (INSTRUMENT) InstrumentCollect();
-            if (DEBUG) std::printf("iteration %lld: queue length %u, edges %u\n", iteration, queue_length, queue_edges);
+            if (INSTRUMENT) InstrumentCollect(in_len, in_edges, bottom_up ? 1 : 0);
+            if (DEBUG) std::printf("iteration %lld (%s): queue length %u, edges %u\n", iteration,
+                                   bottom_up ? "bottom-up" : "top-down", queue_length, queue_edges);
         }
         enactor_stats.iteration = iteration;
         if (retval) return retval;

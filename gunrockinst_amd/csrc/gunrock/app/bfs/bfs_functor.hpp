@@ -27,12 +27,19 @@ template <typename VertexId, typename SizeT, typename Value, typename ProblemDat
 struct BFSFunctor {
     typedef typename ProblemData::DataSlice DataSlice;
 
+    // side-effect-free screen (optional advance hook): is the destination already visited?
+    static __device__ __forceinline__ bool ScreenEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
+                                                      VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
+    {
+        const unsigned word = problem->d_visited_mask[static_cast<unsigned>(d_id) >> 5];
+        return (word & (1u << (d_id & 31))) == 0;        // stale-tolerant: a miss only costs an atomic
+    }
+
     static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
                                                     VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
         unsigned *word = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
         const unsigned bit = 1u << (d_id & 31);
-        if (*word & bit) return false;                    // stale-tolerant screen
         return (atomicOr(word, bit) & bit) == 0;          // exactly one winner per vertex
     }
 

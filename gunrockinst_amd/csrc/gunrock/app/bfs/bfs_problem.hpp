@@ -41,7 +41,16 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         VertexId *d_preds = nullptr;          // parent per vertex (-2 unset, -1 source)
         unsigned *d_visited_mask = nullptr;   // 1 bit per vertex
         VertexId iteration = 0;               // current BSP level (labels written = iteration + 1)
+        // direction-optimizing traversal (reference app/dobfs: d_frontier_map_in/out, dobfs_problem.cuh):
+        unsigned *d_frontier_mask[2] = {nullptr, nullptr};  // 1 bit per vertex: current / next frontier
+        const SizeT *d_inv_row_offsets = nullptr;           // in-neighbour CSR (CSC of the graph)
+        const VertexId *d_inv_column_indices = nullptr;
     };
+
+    // direction-optimizing switches, names from the reference's DOBFS driver (tests/dobfs/test_dobfs.cu:530-534)
+    bool direction_optimizing = false;
+    float alpha = 14.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges
+    float beta = 24.0f;   // bottom-up -> top-down when frontier_vertices * beta < nodes
 
     DataSlice **data_slices = nullptr;  // host copies (by-value kernel arguments), one per GPU
     DataSlice **d_data_slices = nullptr;  // kept for source compatibility; unused (no device-side struct)
@@ -56,13 +65,39 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                 if (ds->d_labels) util::GRError(hipFree(ds->d_labels), "BFSProblem hipFree d_labels failed", __FILE__, __LINE__);
                 if (ds->d_preds) util::GRError(hipFree(ds->d_preds), "BFSProblem hipFree d_preds failed", __FILE__, __LINE__);
                 if (ds->d_visited_mask) util::GRError(hipFree(ds->d_visited_mask), "BFSProblem hipFree d_visited_mask failed", __FILE__, __LINE__);
+                for (int i = 0; i < 2; ++i)
+                    if (ds->d_frontier_mask[i]) util::GRError(hipFree(ds->d_frontier_mask[i]), "BFSProblem hipFree d_frontier_mask failed", __FILE__, __LINE__);
                 delete ds;
             }
             delete[] data_slices;
         }
     }
 
-    SizeT MaskWords() const { return (this->nodes + 31) / 32; }
+    // bitmaps are sized in whole 64-bit words: one wave owns one word in the bottom-up sweep
+    SizeT MaskWords() const { return ((this->nodes + 63) / 64) * 2; }
+
+    // Enable direction-optimizing traversal.  The in-neighbour CSR must stay valid while the problem lives;
+    // for an undirected (symmetric) graph pass the problem's own device arrays (InverseIsSelf()).
+    hipError_t SetInverseGraph(const SizeT *d_inv_row_offsets, const VertexId *d_inv_column_indices,
+                               float alpha_ = 0.0f, float beta_ = 0.0f)
+    {
+        hipError_t retval = hipSuccess;
+        DataSlice *ds = data_slices[0];
+        ds->d_inv_row_offsets = d_inv_row_offsets;
+        ds->d_inv_column_indices = d_inv_column_indices;
+        for (int i = 0; i < 2; ++i)
+            if (!ds->d_frontier_mask[i])
+                GR_CHECK(hipMalloc(&ds->d_frontier_mask[i], sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
+                         "BFSProblem hipMalloc d_frontier_mask failed");
+        if (alpha_ > 0) alpha = alpha_;
+        if (beta_ > 0) beta = beta_;
+        direction_optimizing = true;
+        return retval;
+    }
+    hipError_t InverseIsSelf(float alpha_ = 0.0f, float beta_ = 0.0f)
+    {
+        return SetInverseGraph(this->graph_slices[0]->d_row_offsets, this->graph_slices[0]->d_column_indices, alpha_, beta_);
+    }
 
     hipError_t AllocData()
     {
@@ -74,7 +109,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         GR_CHECK(hipMalloc(&ds->d_labels, sizeof(VertexId) * n), "BFSProblem hipMalloc d_labels failed");
         if (MARK_PREDECESSORS)
             GR_CHECK(hipMalloc(&ds->d_preds, sizeof(VertexId) * n), "BFSProblem hipMalloc d_preds failed");
-        GR_CHECK(hipMalloc(&ds->d_visited_mask, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 1)),
+        GR_CHECK(hipMalloc(&ds->d_visited_mask, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
                  "BFSProblem hipMalloc d_visited_mask failed");
         return retval;
     }
@@ -103,7 +138,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         hipStream_t stream = gs->stream;
         util::Memset(ds->d_labels, static_cast<VertexId>(-1), this->nodes, stream);
         if (MARK_PREDECESSORS) util::Memset(ds->d_preds, static_cast<VertexId>(-2), this->nodes, stream);
-        util::Memset(ds->d_visited_mask, 0u, MaskWords() + 1, stream);
+        util::Memset(ds->d_visited_mask, 0u, MaskWords() + 2, stream);
         ds->iteration = 0;
         src_row[0] = src_row[1] = 0;
         if (src >= 0 && src < this->nodes) {

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <gunrock/util/error_utils.hpp>
 #include <gunrock/util/frontier.hpp>
 
@@ -26,6 +28,9 @@ struct EnactorStats {
     long long kernel_launches = 0;  // INSTRUMENT: operator kernels launched by the last Enact
     double kernel_ms = 0;           // INSTRUMENT: their summed HIP-event durations
     hipError_t retval = hipSuccess;
+    // INSTRUMENT: one record per BSP iteration of the last Enact
+    struct LevelRecord { long long frontier; long long edges; double ms; int kind; };
+    std::vector<LevelRecord> levels;
 };
 
 template <typename SizeT, typename VertexId>
@@ -70,12 +75,13 @@ class EnactorBase {
         return util::GRError(hipEventRecord(ev_end, stream), "EnactorBase hipEventRecord failed", __FILE__, __LINE__);
     }
     // call after the stream has been synchronised
-    void InstrumentCollect()
+    void InstrumentCollect(long long frontier = 0, long long edges = 0, int kind = 0)
     {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) {
             enactor_stats.kernel_ms += ms;
             enactor_stats.kernel_launches += 1;
+            enactor_stats.levels.push_back({frontier, edges, ms, kind});
         }
     }
 
@@ -95,6 +101,7 @@ class EnactorBase {
         enactor_stats.total_edges_queued = 0;
         enactor_stats.kernel_launches = 0;
         enactor_stats.kernel_ms = 0;
+        enactor_stats.levels.clear();
         return retval;
     }
 

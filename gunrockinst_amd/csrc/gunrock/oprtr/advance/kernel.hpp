@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <type_traits>
 
 #include <gunrock/oprtr/frontier_writer.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
@@ -46,6 +47,23 @@ struct KernelPolicy {
     static constexpr int STAGE_CAPACITY = 2 * TILE;       // FrontierWriter staging entries
     static constexpr MODE ADVANCE_MODE = _ADVANCE_MODE;
 };
+
+// Optional functor hook: `static bool ScreenEdge(s_id, d_id, problem, e_id, e_id_in)` -- a side-effect-free
+// pre-test evaluated for all of a thread's edges before any CondEdge runs, so its loads overlap.  Functors
+// without it (the reference's functor shape, bfs_functor.cuh:49-88) are screened by `true`.
+template <typename Functor, typename VertexId, typename DataSlice, typename = void>
+struct HasScreenEdge : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice>
+struct HasScreenEdge<Functor, VertexId, DataSlice,
+                     std::void_t<decltype(Functor::ScreenEdge(VertexId(), VertexId(), static_cast<DataSlice *>(nullptr),
+                                                              VertexId(), VertexId()))>> : std::true_type {};
+
+template <typename Functor, typename VertexId, typename DataSlice>
+__device__ __forceinline__ bool ScreenEdge(VertexId s, VertexId d, DataSlice *slice, VertexId e, VertexId e_in)
+{
+    if constexpr (HasScreenEdge<Functor, VertexId, DataSlice>::value) return Functor::ScreenEdge(s, d, slice, e, e_in);
+    else return true;
+}
 
 template <typename VertexId, typename SizeT>
 struct AdvanceArgs {
@@ -77,6 +95,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     __shared__ VertexId s_vertex[TILE];  // staged vertex id
     __shared__ typename Writer::Storage s_writer;
     __shared__ int s_advance;            // how far the frontier cursor moves after this tile
+    __shared__ int s_owner_count[2][THREADS / util::kWaveSize];
 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
@@ -115,8 +134,11 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
         // ---- stage the covering frontier slice, THREADS entries per round ----
         // s_scan holds the prefix relative to the tile (negative for a row that began in an earlier
         // tile); entries past the slice keep their true value (>= slots), INT_MAX past the frontier.
+        // `owners` counts the staged entries that own at least one slot of this tile (a prefix of the
+        // staged entries, because the degree prefix is increasing).
         int staged = 0;
-        for (int base = 0; base < TILE; base += THREADS) {
+        int owners = 0;
+        for (int base = 0, round = 0; base < TILE; base += THREADS, ++round) {
             const SizeT idx = cursor + base + tid;
             SizeT rel = INT_MAX;
             if (idx < a.in_len) {
@@ -127,35 +149,59 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
                 }
             }
             s_scan[base + tid] = rel;
+            const unsigned long long in_tile = __ballot(rel < slots);
+            if ((tid & (util::kWaveSize - 1)) == 0) s_owner_count[round & 1][tid / util::kWaveSize] = __popcll(in_tile);
             __syncthreads();
             staged = base + THREADS;
-            if (s_scan[staged - 1] >= slots) break;  // uniform: slice ended inside this round
+            int here = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / util::kWaveSize; ++w) here += s_owner_count[round & 1][w];
+            owners += here;
+            if (here < THREADS) break;  // uniform: slice ended inside this round
         }
         if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
             Writer::template Flush<true>(s_writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
         }
 
-        // ---- expand: lane-strided slots => coalesced column_indices reads ----
+        // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
+        // lane-strided slots => one wave-instruction reads 256 contiguous bytes of column_indices
+        SizeT edge[ITEMS];
+        VertexId src[ITEMS];
+        VertexId dst[ITEMS];
+        bool live[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {  // owner search in LDS
+            const int slot = k * THREADS + tid;
+            live[k] = slot < slots;
+            int lo = 0, hi = owners;  // s_scan[lo] <= slot < s_scan[hi] (hi == owners: past the slice)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_scan[mid] <= slot) lo = mid; else hi = mid;
+            }
+            edge[k] = s_row[lo] + (slot - s_scan[lo]);
+            src[k] = s_vertex[lo];
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(-1);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)  // side-effect-free screen: all status loads in flight together
+            live[k] = live[k] && ScreenEdge<Functor>(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
+            live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
+        int mine = 0;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
-            const int slot = k * THREADS + tid;
-            bool accept = false;
-            VertexId dst = 0;
-            if (slot < slots) {
-                int lo = 0, hi = staged;  // s_scan[lo] <= slot < s_scan[hi] (or hi == staged)
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_scan[mid] <= slot) lo = mid; else hi = mid;
-                }
-                const SizeT edge = s_row[lo] + (slot - s_scan[lo]);
-                const VertexId src = s_vertex[lo];
-                dst = a.d_column_indices[edge];
-                if (Functor::CondEdge(src, dst, &slice, edge, slot0 + slot)) {
-                    Functor::ApplyEdge(src, dst, &slice, edge, slot0 + slot);
-                    accept = true;
-                }
+            if (live[k]) {
+                Functor::ApplyEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
+                ++mine;
             }
-            Writer::Append(s_writer, accept, dst);
+        }
+        {   // one LDS reservation per wave per tile
+            int pos = Writer::Reserve(s_writer, mine);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k)
+                if (live[k]) s_writer.buf[pos++] = dst[k];
         }
 
         // ---- move the cursor to the owner of the next tile's first slot ----

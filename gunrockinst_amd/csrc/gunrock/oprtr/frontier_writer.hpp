@@ -51,6 +51,19 @@ struct FrontierWriter {
         if (pred) st.buf[base + util::RankInMask(m)] = v;
     }
 
+    // Wave-aggregated reservation of `mine` slots per lane: one LDS atomic per wave.  Every lane of the wave
+    // must call; returns the lane's first slot in buf.
+    static __device__ __forceinline__ int Reserve(Storage &st, int mine)
+    {
+        const int incl = util::WaveInclusiveSum(mine);
+        const int total = __shfl(incl, util::kWaveSize - 1, util::kWaveSize);
+        int base = 0;
+        if (total == 0) return 0;  // wave-uniform
+        if (util::LaneId() == util::kWaveSize - 1) base = atomicAdd(&st.count, total);
+        base = __shfl(base, util::kWaveSize - 1, util::kWaveSize);
+        return base + incl - mine;
+    }
+
     // Number of staged entries.  Call it between two workgroup barriers that separate it from any
     // Append (so every thread reads the same value), then hand it to Flush.
     static __device__ __forceinline__ int Count(const Storage &st) { return st.count; }

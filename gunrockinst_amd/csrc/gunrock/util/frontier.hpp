@@ -41,7 +41,8 @@ __host__ __device__ __forceinline__ unsigned TailEdges(unsigned long long t) { r
 
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail for frontier conversions
+    static constexpr int kAux = 4;
     unsigned long long *d_tail = nullptr;  // [kSlots] packed (edges<<32 | vertices)
     int *d_overflow = nullptr;             // set when a writer ran out of queue capacity
     unsigned long long *h_tail = nullptr;  // pinned mirror for the per-step read-back
@@ -85,6 +86,23 @@ struct WorkProgress {
         GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetTail sync failed");
         count = TailCount(h_tail[slot & 3]);
         edges = TailEdges(h_tail[slot & 3]);
+        return retval;
+    }
+
+    unsigned long long *AuxTail() { return d_tail + kAux; }
+    hipError_t ClearAux(hipStream_t stream)
+    {
+        return GRError(hipMemsetAsync(d_tail + kAux, 0, sizeof(unsigned long long), stream),
+                       "WorkProgress ClearAux failed", __FILE__, __LINE__);
+    }
+    hipError_t GetAux(unsigned &count, unsigned &edges, hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemcpyAsync(h_tail + kAux, d_tail + kAux, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream),
+                 "WorkProgress GetAux copy failed");
+        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetAux sync failed");
+        count = TailCount(h_tail[kAux]);
+        edges = TailEdges(h_tail[kAux]);
         return retval;
     }
 

@@ -29,9 +29,11 @@ struct BfsRunner {
     virtual ~BfsRunner() {}
     virtual hipError_t Init(const Csr<int, int, int> &g) = 0;
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
+    virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
     virtual void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) = 0;
+    virtual int Trace(int max_levels, long long *frontier, long long *edges, double *ms, int *kind) = 0;
     virtual hipError_t Extract(int *labels, int *preds) = 0;
     virtual void DeviceResults(int **labels, int **preds) = 0;
 };
@@ -59,6 +61,12 @@ struct BfsRunnerT : BfsRunner {
     {
         return problem.InitFromDevice(nodes, edges, d_ro, d_ci);
     }
+    hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) override
+    {
+        if (!problem.data_slices) return hipErrorNotInitialized;
+        if (!d_iro || !d_ici) return problem.InverseIsSelf(alpha, beta);
+        return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
+    }
     hipError_t Reset(int src, double queue_sizing) override
     {
         return problem.Reset(src, enactor.GetFrontierType(), queue_sizing);
@@ -80,6 +88,18 @@ struct BfsRunnerT : BfsRunner {
     {
         enactor.GetStatistics(queued, depth, duty);
         enactor.GetKernelStatistics(launches, kernel_ms);
+    }
+    int Trace(int max_levels, long long *frontier, long long *edges, double *ms, int *kind) override
+    {
+        const auto &t = enactor.GetLevelTrace();
+        int n = static_cast<int>(t.size()) < max_levels ? static_cast<int>(t.size()) : max_levels;
+        for (int i = 0; i < n; ++i) {
+            if (frontier) frontier[i] = t[i].frontier;
+            if (edges) edges[i] = t[i].edges;
+            if (ms) ms[i] = t[i].ms;
+            if (kind) kind[i] = t[i].kind;
+        }
+        return static_cast<int>(t.size());
     }
     hipError_t Extract(int *labels, int *preds) override { return problem.Extract(labels, preds); }
     void DeviceResults(int **labels, int **preds) override
@@ -165,6 +185,13 @@ int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, in
     return static_cast<int>(p->runner->InitDevice(nodes, edges, d_row_offsets, d_col_indices));
 }
 
+int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const int *d_inv_col_indices, float alpha,
+                              float beta)
+{
+    if (!p) return -1;
+    return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, alpha, beta));
+}
+
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing)
 {
     if (!p) return -1;
@@ -190,6 +217,12 @@ int grx_bfs_stats(grx_bfs *p, long long *total_queued, long long *search_depth, 
     if (kernel_launches) *kernel_launches = l;
     if (kernel_ms) *kernel_ms = kms;
     return 0;
+}
+
+int grx_bfs_level_trace(grx_bfs *p, int max_levels, long long *frontier, long long *edges, double *ms, int *kind)
+{
+    if (!p || max_levels < 0) return -1;
+    return p->runner->Trace(max_levels, frontier, edges, ms, kind);
 }
 
 int grx_bfs_extract(grx_bfs *p, int *h_labels, int *h_preds)

@@ -68,15 +68,27 @@ int grx_bfs_create(grx_bfs **out, int mark_pred, int idempotence, int instrument
 int grx_bfs_init(grx_bfs *p, int nodes, int edges, const int *row_offsets, const int *col_indices);
 /* same, for a CSR that already lives in HBM (pointers are borrowed for the life of the handle) */
 int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices);
+/* Enable direction-optimizing traversal (reference app/dobfs: DOBFSProblem::Init takes the graph AND its inverse,
+ * dobfs_problem.cuh; alpha/beta as in tests/dobfs/test_dobfs.cu:530-534).  d_inv_* is the in-neighbour CSR in HBM
+ * (borrowed); pass NULL, NULL when the graph is undirected/symmetric to reuse the forward arrays.  alpha/beta <= 0
+ * keep the defaults.  Takes effect with traversal_mode = 2 in grx_bfs_enact.  Call after init. */
+int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const int *d_inv_col_indices,
+                              float alpha, float beta);
 /* BFSProblem::Reset(src, frontier_type, queue_sizing) (reference bfs_problem.cuh:272-360) */
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing);
-/* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579),
+/* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579);
+ * traversal_mode 0 = load-balanced top-down, 1 = reserved (TWC), 2 = direction-optimizing;
  * bracketed by HIP events on the problem's stream like the reference's GpuTimer (test_bfs.cu:408-438) */
 int grx_bfs_enact(grx_bfs *p, int src, int max_grid_size, int traversal_mode, float *elapsed_ms);
 /* BFSEnactor::GetStatistics (reference bfs_enactor.cuh:173-186) plus, when instrumented, operator-kernel
  * launch count and summed kernel time of the last Enact */
 int grx_bfs_stats(grx_bfs *p, long long *total_queued, long long *search_depth, double *avg_duty,
                   long long *kernel_launches, double *kernel_ms);
+/* instrumented enactors only: per-BSP-iteration record of the last Enact (input frontier length, its edge count,
+ * operator kernel milliseconds, operator kind: 0 = top-down advance, 1 = bottom-up advance).  Fills up to
+ * max_levels entries and returns the number of iterations recorded.  The `--v` per-iteration printout of the
+ * reference driver (bfs_enactor.cuh:333-338) in data form. */
+int grx_bfs_level_trace(grx_bfs *p, int max_levels, long long *frontier, long long *edges, double *ms, int *kind);
 /* BFSProblem::Extract(h_labels, h_preds) (reference bfs_problem.cuh:144-177); h_preds may be NULL */
 int grx_bfs_extract(grx_bfs *p, int *h_labels, int *h_preds);
 /* device result arrays (valid until destroy / next init) */

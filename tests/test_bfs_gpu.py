@@ -13,10 +13,12 @@ pytestmark = pytest.mark.gpu
 MODES = [(False, False), (True, False), (False, True), (True, True)]
 
 
-def _run(g, src, mark_pred, idempotence, instrument=False, queue_sizing=1.0):
+def _run(g, src, mark_pred, idempotence, instrument=False, queue_sizing=1.0, mode=0, alpha=0.0, beta=0.0):
     p = ga.BfsProblem(mark_pred, idempotence, instrument).init(g.nodes, g.row_offsets, g.col_indices)
+    if mode == 2:
+        p.set_inverse_graph(alpha=alpha, beta=beta)      # symmetric graphs only
     p.reset(src, queue_sizing)
-    ms = p.enact(src)
+    ms = p.enact(src, traversal_mode=mode)
     labels, preds = p.extract()
     st = p.stats()
     p.close()
@@ -141,3 +143,54 @@ def test_reset_and_rerun_same_problem():
         assert np.array_equal(labels, o.bfs(g, src)[0])
         assert o.check_bfs_preds(g, src, labels, preds) == 0
     p.close()
+
+
+# ---------------- direction-optimizing traversal (traversal_mode = 2) ----------------
+@pytest.mark.parametrize("mark_pred,idempotence", MODES)
+def test_dobfs_bips_all_modes(golden, golden_dir, mark_pred, idempotence):
+    g = o.build_market(os.path.join(golden_dir, "bips98_606.mtx"), undirected=True)
+    for src in (0, 566):
+        for alpha, beta in [(0.0, 0.0), (1e9, 1.0), (1e9, 1e9)]:   # default, always bottom-up, flip-flop every level
+            labels, preds, st, _ = _run(g, src, mark_pred, idempotence, mode=2, alpha=alpha, beta=beta)
+            _check(g, src, labels, preds, st)
+
+
+@pytest.mark.parametrize("scale,ef", [(10, 8), (14, 8), (16, 16), (18, 8)])
+def test_dobfs_rmat_parity(scale, ef):
+    g = o.rmat_seeded(scale, ef << scale)
+    src, _ = o.highest_degree_node(g)
+    rng = np.random.default_rng(scale + 100)
+    deg = np.diff(g.row_offsets)
+    others = rng.choice(np.nonzero(deg > 0)[0], 3)
+    for s in [src] + others.tolist():
+        for alpha, beta in [(0.0, 0.0), (1e9, 1.0)]:
+            labels, preds, st, _ = _run(g, int(s), True, True, mode=2, alpha=alpha, beta=beta, instrument=True)
+            _check(g, int(s), labels, preds, st)
+
+
+def test_dobfs_long_rows_take_the_wave_sweep():
+    # complete bipartite-ish: 300 left vertices each adjacent to 3000 right vertices; source on the right side.
+    # Bottom-up from level 1: left vertices find the source only deep in their list (source id is the LAST right id).
+    L, R = 300, 3000
+    rows = np.repeat(np.arange(L, dtype=np.int32), R)
+    cols = np.tile(np.arange(L, L + R, dtype=np.int32), L)
+    g0 = ga.HostGraph.from_coo(L + R, np.concatenate([rows, cols]), np.concatenate([cols, rows]))
+    g = o.Csr(g0.nodes, g0.row_offsets.copy(), g0.col_indices.copy())
+    src = L + R - 1
+    labels, preds, st, _ = _run(g, src, True, False, mode=2, alpha=1e9, beta=1.0)
+    _check(g, src, labels, preds, st)
+
+
+def test_dobfs_edge_cases():
+    g = o.Csr(1, [0, 0], [])
+    labels, _, st, _ = _run(g, 0, False, True, mode=2, alpha=1e9, beta=1.0)
+    assert labels.tolist() == [0]
+    n = 300                                              # path graph, symmetric, always bottom-up
+    rows = np.concatenate([np.arange(n - 1), np.arange(1, n)]).astype(np.int32)
+    cols = np.concatenate([np.arange(1, n), np.arange(n - 1)]).astype(np.int32)
+    g0 = ga.HostGraph.from_coo(n, rows, cols)
+    g = o.Csr(n, g0.row_offsets.copy(), g0.col_indices.copy())
+    labels, preds, st, _ = _run(g, 0, True, True, mode=2, alpha=1e9, beta=1.0)
+    _check(g, 0, labels, preds, st)
+    labels, preds, st, _ = _run(g, n // 2, True, True, mode=2, alpha=1e9, beta=1e9)
+    _check(g, n // 2, labels, preds, st)
