@@ -92,6 +92,16 @@ _SIGNATURES = {
     "grx_bfs_extract": (C.c_int, [C.c_void_p, i32p, i32p]),
     "grx_bfs_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "grx_bfs_destroy": (None, [C.c_void_p]),
+    "grx_cc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "grx_cc_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
+    "grx_cc_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_cc_reset": (C.c_int, [C.c_void_p]),
+    "grx_cc_enact": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "grx_cc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                               C.POINTER(C.c_double)]),
+    "grx_cc_extract": (C.c_int, [C.c_void_p, i32p, C.POINTER(C.c_uint)]),
+    "grx_cc_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_cc_destroy": (None, [C.c_void_p]),
     "grx_bfs_count_visited": (None, [C.c_int, i32p, i32p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "grx_version": (C.c_char_p, []),
 }
@@ -327,4 +337,75 @@ def gunrock_bfs(nodes, row_offsets, col_indices, src=0, mark_pred=False, idempot
     cfg.src_node, cfg.device, cfg.queue_size, cfg.src_mode = src, device, queue_size, src_mode
     dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
     lib().gunrock_bfs_func(C.byref(gout), C.byref(gin), cfg, dt)
+    return _take_node_values(gout, nodes, np.int32)
+
+
+class CcProblem:
+    """CCProblem + CCEnactor behind the handle C ABI."""
+
+    def __init__(self, instrument=False, device=0):
+        self._h = C.c_void_p()
+        _check(lib().grx_cc_create(C.byref(self._h), int(instrument), device), "grx_cc_create")
+        self.nodes = 0
+
+    def init(self, nodes, row_offsets, col_indices):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        self.nodes = int(nodes)
+        _check(lib().grx_cc_init(self._h, nodes, ci.shape[0], _p(ro), _p(ci)), "CCProblem::Init")
+        return self
+
+    def init_device(self, nodes, edges, d_row_offsets, d_col_indices):
+        self.nodes = int(nodes)
+        _check(lib().grx_cc_init_device(self._h, nodes, edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices)),
+               "CCProblem::Init(device)")
+        return self
+
+    def reset(self):
+        _check(lib().grx_cc_reset(self._h), "CCProblem::Reset")
+
+    def enact(self, max_grid_size=0):
+        ms = C.c_float()
+        _check(lib().grx_cc_enact(self._h, max_grid_size, C.byref(ms)), "CCEnactor::Enact")
+        return float(ms.value)
+
+    def stats(self):
+        es, vs, l = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        k = C.c_double()
+        _check(lib().grx_cc_stats(self._h, C.byref(es), C.byref(vs), C.byref(l), C.byref(k)), "grx_cc_stats")
+        return {"edge_sweeps": es.value, "vertex_sweeps": vs.value, "kernel_launches": l.value, "kernel_ms": k.value}
+
+    def extract(self):
+        ids = np.empty(max(self.nodes, 1), dtype=np.int32)
+        nc = C.c_uint()
+        _check(lib().grx_cc_extract(self._h, _p(ids), C.byref(nc)), "CCProblem::Extract")
+        return ids[:self.nodes], int(nc.value)
+
+    def device_results(self):
+        d = C.c_void_p()
+        _check(lib().grx_cc_device_results(self._h, C.byref(d)), "grx_cc_device_results")
+        return d.value
+
+    def close(self):
+        if self._h:
+            lib().grx_cc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gunrock_cc(nodes, row_offsets, col_indices, device=0):
+    """Call gunrock_cc_func as reference shared_lib_tests/test_cc.c does; returns the component ids."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    gin = _graph_struct(nodes, ro, ci)
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.device = device
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
+    lib().gunrock_cc_func(C.byref(gout), C.byref(gin), cfg, dt)
     return _take_node_values(gout, nodes, np.int32)

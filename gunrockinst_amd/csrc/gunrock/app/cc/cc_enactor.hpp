@@ -1,0 +1,131 @@
+// app/cc/cc_enactor.hpp -- host loop for connected components.
+//
+// Public contract of the reference's CCEnactor (gunrock/app/cc/cc_enactor.cuh:36-919):
+//   template <bool INSTRUMENT> class CCEnactor : EnactorBase;  Enact<CCProblem>(problem, max_grid_size)
+//   GetStatistics(total_queued, num_iter, avg_duty)                                           (:140-160)
+// Schedule kept from EnactCC (:165-873): HookInit over edges -> PtrJump over vertices until stable ->
+// UpdateMask -> repeat { HookMax over edges; stop if nothing hooked; PtrJumpMask until stable; PtrJumpUnmask;
+// UpdateMask }.  Every sweep is the filter operator in its non-compacting form with one of the functors of
+// cc_functor.hpp (the reference launches filter::Kernel with filtering_flag=false the same way, :407-424).
+// Differences: the two convergence flags live next to each other in HBM and are reset by one 8-byte
+// hipMemsetAsync instead of a blocking 4-byte H2D copy per sweep (:445-450, 532-538); sweeps take the identity
+// queue (NULL) rather than reading an iota array; launch grids fill 256 CUs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <gunrock/app/cc/cc_functor.hpp>
+#include <gunrock/app/cc/cc_problem.hpp>
+#include <gunrock/app/enactor_base.hpp>
+#include <gunrock/oprtr/filter/kernel.hpp>
+
+namespace gunrock {
+namespace app {
+namespace cc {
+
+template <bool INSTRUMENT>
+class CCEnactor : public EnactorBase {
+   public:
+    explicit CCEnactor(bool DEBUG = false) : EnactorBase(EDGE_FRONTIERS, DEBUG) {}
+    ~CCEnactor() override {}
+
+    long long edge_sweeps = 0;    // I_h of SURVEY 8(d)
+    long long vertex_sweeps = 0;  // I_j
+
+    void GetStatistics(long long &total_queued, long long &num_iter, double &avg_duty)
+    {
+        total_queued = enactor_stats.total_queued;
+        num_iter = enactor_stats.iteration;
+        avg_duty = 0.0;
+    }
+    void GetKernelStatistics(long long &launches, double &kernel_ms)
+    {
+        launches = enactor_stats.kernel_launches;
+        kernel_ms = enactor_stats.kernel_ms;
+    }
+
+    typedef oprtr::filter::KernelPolicy<256, 4, 8> FilterPolicy;
+
+    template <typename CCProblem>
+    hipError_t Enact(CCProblem *problem, int max_grid_size = 0)
+    {
+        typedef typename CCProblem::VertexId VertexId;
+        typedef typename CCProblem::SizeT SizeT;
+        typedef typename CCProblem::Value Value;
+        typedef UpdateMaskFunctor<VertexId, SizeT, Value, CCProblem> UpdateMask;
+        typedef HookInitFunctor<VertexId, SizeT, Value, CCProblem> HookInit;
+        typedef HookMaxFunctor<VertexId, SizeT, Value, CCProblem> HookMax;
+        typedef PtrJumpFunctor<VertexId, SizeT, Value, CCProblem> PtrJump;
+        typedef PtrJumpMaskFunctor<VertexId, SizeT, Value, CCProblem> PtrJumpMask;
+        typedef PtrJumpUnmaskFunctor<VertexId, SizeT, Value, CCProblem> PtrJumpUnmask;
+
+        hipError_t retval = hipSuccess;
+        if ((retval = EnactorBase::Setup(max_grid_size, 8, 8))) return retval;
+        const int grid = enactor_stats.filter_grid_size * 2;
+        typename CCProblem::DataSlice *ds = problem->data_slices[0];
+        hipStream_t stream = problem->graph_slices[0]->stream;
+        const SizeT n = problem->nodes, m = problem->edges;
+        edge_sweeps = vertex_sweeps = 0;
+        if (n <= 0) return retval;
+
+#define GR_CC_SWEEP(Functor, count, kind)                                                                            \
+    do {                                                                                                             \
+        if (INSTRUMENT && (retval = InstrumentBegin(stream))) return retval;                                         \
+        if ((retval = oprtr::filter::LaunchApply<FilterPolicy, CCProblem, Functor>(nullptr, (count), nullptr, *ds,  \
+                                                                                    grid, stream)))                 \
+            return retval;                                                                                           \
+        if (INSTRUMENT) {                                                                                            \
+            if ((retval = InstrumentEnd(stream))) return retval;                                                     \
+            GR_CHECK(hipStreamSynchronize(stream), "CCEnactor sync failed");                                         \
+            InstrumentCollect((count), 0, (kind));                                                                   \
+        }                                                                                                            \
+        if (kind) ++edge_sweeps; else ++vertex_sweeps;                                                               \
+        enactor_stats.total_queued += (count);                                                                       \
+    } while (0)
+
+        // flags: set both to 1, run the sweep, read them back (one 8-byte copy)
+        auto arm = [&]() -> hipError_t {
+            problem->h_flags[0] = problem->h_flags[1] = 1;
+            return util::GRError(hipMemcpyAsync(ds->d_vertex_flag, problem->h_flags, sizeof(int) * 2, hipMemcpyHostToDevice, stream),
+                                 "CCEnactor arm flags failed", __FILE__, __LINE__);
+        };
+        auto poll = [&]() -> hipError_t {
+            hipError_t rc = util::GRError(hipMemcpyAsync(problem->h_flags, ds->d_vertex_flag, sizeof(int) * 2, hipMemcpyDeviceToHost, stream),
+                                          "CCEnactor read flags failed", __FILE__, __LINE__);
+            if (rc) return rc;
+            return util::GRError(hipStreamSynchronize(stream), "CCEnactor sync failed", __FILE__, __LINE__);
+        };
+
+        if (m > 0) GR_CC_SWEEP(HookInit, m, 1);
+        for (;;) {  // first pointer-jumping round (cc_enactor.cuh:442-493)
+            if ((retval = arm())) return retval;
+            GR_CC_SWEEP(PtrJump, n, 0);
+            if ((retval = poll())) return retval;
+            ++enactor_stats.iteration;
+            if (problem->h_flags[0]) break;
+        }
+        GR_CC_SWEEP(UpdateMask, n, 0);
+
+        while (m > 0) {  // cc_enactor.cuh:524-862
+            if ((retval = arm())) return retval;
+            GR_CC_SWEEP(HookMax, m, 1);
+            if ((retval = poll())) return retval;
+            ++enactor_stats.iteration;
+            if (problem->h_flags[1]) break;  // no edge hooked anything: done
+            for (;;) {
+                if ((retval = arm())) return retval;
+                GR_CC_SWEEP(PtrJumpMask, n, 0);
+                if ((retval = poll())) return retval;
+                if (problem->h_flags[0]) break;
+            }
+            GR_CC_SWEEP(PtrJumpUnmask, n, 0);
+            GR_CC_SWEEP(UpdateMask, n, 0);
+        }
+#undef GR_CC_SWEEP
+        return retval;
+    }
+};
+
+}  // namespace cc
+}  // namespace app
+}  // namespace gunrock

@@ -1,0 +1,144 @@
+// app/cc/cc_functor.hpp -- the seven filter functors of the hook / pointer-jump algorithm.
+//
+// Names, signatures and per-element effects follow the reference (gunrock/app/cc/cc_functor.cuh:18-410);
+// `node` is an EDGE id for the hook functors and a VERTEX id for the others.  All writes store a strictly
+// smaller id into a larger slot, so component_ids[v] <= v always holds and the smallest vertex of a component
+// is never overwritten: the fixed point is component_ids[v] = min id of v's component for any interleaving
+// (SURVEY 8(a) C3).  Reads that race with other lanes' writes go through agent-scope relaxed loads so a sweep
+// sees hooks made earlier in the same launch where the hardware allows; correctness never depends on it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace gunrock {
+namespace app {
+namespace cc {
+
+template <typename T>
+__device__ __forceinline__ T LoadFresh(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void StoreFresh(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// mask[v] = (v is its own parent) ? 0 : 1      -- cc_functor.cuh:30-47
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct UpdateMaskFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        problem->d_masks[node] = (problem->d_component_ids[node] == node) ? 0 : 1;
+    }
+};
+
+// first hook: parent[max(from,to)] = min(from,to)      -- cc_functor.cuh:78-104
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookInitFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId edge, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        const VertexId f = problem->d_froms[edge], t = problem->d_tos[edge];
+        if (f == t) return;
+        const VertexId hi = f > t ? f : t, lo = f > t ? t : f;
+        StoreFresh(problem->d_component_ids + hi, lo);
+    }
+};
+
+// hook the larger root under the smaller one; an edge whose ends share a root is marked done -- cc_functor.cuh:172-216
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookMaxFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId edge, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        if (problem->d_marks[edge]) return;
+        const VertexId pf = LoadFresh(problem->d_component_ids + problem->d_froms[edge]);
+        const VertexId pt = LoadFresh(problem->d_component_ids + problem->d_tos[edge]);
+        if (pf == pt) {
+            problem->d_marks[edge] = 1;
+        } else {
+            const VertexId hi = pf > pt ? pf : pt, lo = pf > pt ? pt : pf;
+            StoreFresh(problem->d_component_ids + hi, lo);
+            StoreFresh(problem->d_edge_flag, 0);
+        }
+    }
+};
+
+// mirrored variant kept for API completeness (unused by the enactor, as in the reference: cc_enactor.cuh:540-559)
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookMinFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId edge, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        if (problem->d_marks[edge]) return;
+        const VertexId pf = LoadFresh(problem->d_component_ids + problem->d_froms[edge]);
+        const VertexId pt = LoadFresh(problem->d_component_ids + problem->d_tos[edge]);
+        if (pf == pt) {
+            problem->d_marks[edge] = 1;
+        } else {
+            const VertexId hi = pf > pt ? pf : pt, lo = pf > pt ? pt : pf;
+            StoreFresh(problem->d_component_ids + lo, hi);
+            StoreFresh(problem->d_edge_flag, 0);
+        }
+    }
+};
+
+// parent[v] = parent[parent[v]]      -- cc_functor.cuh:230-262
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct PtrJumpFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        const VertexId parent = LoadFresh(problem->d_component_ids + node);
+        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        if (parent != grand) {
+            StoreFresh(problem->d_vertex_flag, 0);
+            StoreFresh(problem->d_component_ids + node, grand);
+        }
+    }
+};
+
+// the same for vertices whose mask is 0; one already at a root gets mask -1      -- cc_functor.cuh:276-313
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct PtrJumpMaskFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        if (problem->d_masks[node] != 0) return;
+        const VertexId parent = LoadFresh(problem->d_component_ids + node);
+        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        if (parent != grand) {
+            StoreFresh(problem->d_vertex_flag, 0);
+            StoreFresh(problem->d_component_ids + node, grand);
+        } else {
+            problem->d_masks[node] = -1;
+        }
+    }
+};
+
+// one jump for vertices whose mask is 1      -- cc_functor.cuh:327-352
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct PtrJumpUnmaskFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        if (problem->d_masks[node] != 1) return;
+        const VertexId parent = LoadFresh(problem->d_component_ids + node);
+        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        StoreFresh(problem->d_component_ids + node, grand);
+    }
+};
+
+}  // namespace cc
+}  // namespace app
+}  // namespace gunrock

@@ -1,0 +1,182 @@
+// app/cc/cc_problem.hpp -- device data for connected components (Soman hook + pointer-jump).
+//
+// Same contract as the reference's CCProblem (gunrock/app/cc/cc_problem.cuh:36-440):
+//   DataSlice { d_component_ids, d_masks, d_marks, d_froms, d_tos, d_vertex_flag, d_edge_flag }   (:48-57)
+//   Init(stream_from_host, graph, num_gpus): uploads the CSR and the edge list                     (:221-345)
+//   Reset(frontier_type): component ids = iota, masks = 0, marks = false                            (:361-440)
+//   Extract(h_component_ids): copies ids, counts roots into num_components                          (:144-175)
+//   ComputeCCHistogram(ids, roots, histogram)                                                        (:185-210)
+// MI355X-first differences: the edge list is not a host-built copy (cc_problem.cuh:262-272 builds and uploads
+// 2 x m ints): d_tos IS the CSR column array and d_froms is expanded on the GPU from the row offsets; the
+// iota "queues" the reference stores and re-reads every sweep (:386-408) do not exist (the filter operator
+// takes a NULL = identity queue); ComputeCCHistogram is O(n) instead of O(n x components).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include <gunrock/app/problem_base.hpp>
+#include <gunrock/util/device_intrinsics.hpp>
+#include <gunrock/util/memset_kernel.hpp>
+
+namespace gunrock {
+namespace app {
+namespace cc {
+
+// froms[e] = row of edge e.  One wave per 64 rows: short rows are written by their lane, long rows by the wave.
+template <typename VertexId, typename SizeT>
+__global__ void ExpandRowsKernel(const SizeT *d_row_offsets, SizeT nodes, VertexId *d_froms)
+{
+    const unsigned lane = util::LaneId();
+    const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize;
+    const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
+    const long long groups = (static_cast<long long>(nodes) + 63) / 64;
+    for (long long g = wave0; g < groups; g += nwaves) {
+        const long long v = g * 64 + lane;
+        SizeT b = 0, e = 0;
+        if (v < nodes) { b = d_row_offsets[v]; e = d_row_offsets[v + 1]; }
+        const bool long_row = (e - b) > 16;
+        if (!long_row) for (SizeT i = b; i < e; ++i) d_froms[i] = static_cast<VertexId>(v);
+        unsigned long long todo = __ballot(long_row);
+        while (todo) {
+            const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+            const SizeT lb = __shfl(b, leader, util::kWaveSize), le = __shfl(e, leader, util::kWaveSize);
+            const VertexId lv = static_cast<VertexId>(g * 64 + leader);
+            for (SizeT i = lb + static_cast<SizeT>(lane); i < le; i += util::kWaveSize) d_froms[i] = lv;
+            todo &= todo - 1;
+        }
+    }
+}
+
+template <typename _VertexId, typename _SizeT, typename _Value, bool _USE_DOUBLE_BUFFER>
+struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
+    typedef ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> Base;
+    typedef _VertexId VertexId;
+    typedef _SizeT SizeT;
+    typedef _Value Value;
+    static constexpr bool ENABLE_IDEMPOTENCE = false;
+    static constexpr bool MARK_PREDECESSORS = false;
+
+    struct DataSlice {
+        VertexId *d_component_ids = nullptr;  // parent pointer per vertex; converges to the component's min id
+        int *d_masks = nullptr;               // 0 = root candidate, 1 = non-root, -1 = settled root
+        unsigned char *d_marks = nullptr;     // per edge: both ends already in one tree
+        VertexId *d_froms = nullptr;          // per edge: source vertex
+        const VertexId *d_tos = nullptr;      // per edge: destination vertex (= CSR column_indices)
+        int *d_vertex_flag = nullptr;         // cleared by a pointer-jump sweep that changed something
+        int *d_edge_flag = nullptr;           // cleared by a hook sweep that hooked something
+    };
+
+    DataSlice **data_slices = nullptr;
+    unsigned int num_components = 0;
+    int *h_flags = nullptr;  // pinned: [0] vertex flag, [1] edge flag
+
+    ~CCProblem() override
+    {
+        if (data_slices) {
+            DataSlice *ds = data_slices[0];
+            if (ds) {
+                if (ds->d_component_ids) util::GRError(hipFree(ds->d_component_ids), "CCProblem hipFree failed", __FILE__, __LINE__);
+                if (ds->d_masks) util::GRError(hipFree(ds->d_masks), "CCProblem hipFree failed", __FILE__, __LINE__);
+                if (ds->d_marks) util::GRError(hipFree(ds->d_marks), "CCProblem hipFree failed", __FILE__, __LINE__);
+                if (ds->d_froms) util::GRError(hipFree(ds->d_froms), "CCProblem hipFree failed", __FILE__, __LINE__);
+                if (ds->d_vertex_flag) util::GRError(hipFree(ds->d_vertex_flag), "CCProblem hipFree failed", __FILE__, __LINE__);
+                delete ds;
+            }
+            delete[] data_slices;
+        }
+        if (h_flags) util::GRError(hipHostFree(h_flags), "CCProblem hipHostFree failed", __FILE__, __LINE__);
+    }
+
+    hipError_t AllocData()
+    {
+        hipError_t retval = hipSuccess;
+        data_slices = new DataSlice *[1];
+        data_slices[0] = new DataSlice();
+        DataSlice *ds = data_slices[0];
+        GraphSlice<VertexId, SizeT, Value> *gs = this->graph_slices[0];
+        const size_t n = static_cast<size_t>(this->nodes > 0 ? this->nodes : 1);
+        const size_t m = static_cast<size_t>(this->edges > 0 ? this->edges : 1);
+        GR_CHECK(hipMalloc(&ds->d_component_ids, sizeof(VertexId) * n), "CCProblem hipMalloc d_component_ids failed");
+        GR_CHECK(hipMalloc(&ds->d_masks, sizeof(int) * n), "CCProblem hipMalloc d_masks failed");
+        GR_CHECK(hipMalloc(&ds->d_marks, m), "CCProblem hipMalloc d_marks failed");
+        GR_CHECK(hipMalloc(&ds->d_froms, sizeof(VertexId) * m), "CCProblem hipMalloc d_froms failed");
+        GR_CHECK(hipMalloc(&ds->d_vertex_flag, sizeof(int) * 2), "CCProblem hipMalloc flags failed");
+        ds->d_edge_flag = ds->d_vertex_flag + 1;
+        ds->d_tos = gs->d_column_indices;
+        GR_CHECK(hipHostMalloc(&h_flags, sizeof(int) * 2, hipHostMallocDefault), "CCProblem hipHostMalloc failed");
+        if (this->nodes > 0) {
+            hipLaunchKernelGGL((ExpandRowsKernel<VertexId, SizeT>), dim3(2048), dim3(256), 0, gs->stream, gs->d_row_offsets,
+                               this->nodes, ds->d_froms);
+            GR_CHECK(hipGetLastError(), "ExpandRowsKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(gs->stream), "ExpandRowsKernel failed");
+        }
+        return retval;
+    }
+
+    hipError_t Init(bool stream_from_host, const Csr<VertexId, Value, SizeT> &graph, int num_gpus = 1)
+    {
+        hipError_t retval = hipSuccess;
+        if ((retval = Base::Init(stream_from_host, graph, num_gpus))) return retval;
+        return AllocData();
+    }
+
+    hipError_t InitFromDevice(SizeT nodes, SizeT edges, SizeT *d_row_offsets, VertexId *d_column_indices)
+    {
+        hipError_t retval = hipSuccess;
+        if ((retval = Base::InitFromDevice(nodes, edges, d_row_offsets, d_column_indices))) return retval;
+        return AllocData();
+    }
+
+    hipError_t Reset(FrontierType /*frontier_type*/, double /*queue_sizing*/ = 1.0)
+    {
+        hipError_t retval = hipSuccess;
+        DataSlice *ds = data_slices[0];
+        hipStream_t stream = this->graph_slices[0]->stream;
+        util::MemsetIdx(ds->d_component_ids, this->nodes, stream);
+        util::Memset(ds->d_masks, 0, this->nodes, stream);
+        GR_CHECK(hipMemsetAsync(ds->d_marks, 0, static_cast<size_t>(this->edges > 0 ? this->edges : 1), stream),
+                 "CCProblem memset d_marks failed");
+        GR_CHECK(hipMemsetAsync(ds->d_vertex_flag, 0, sizeof(int) * 2, stream), "CCProblem memset flags failed");
+        GR_CHECK(hipStreamSynchronize(stream), "CCProblem Reset sync failed");
+        num_components = 0;
+        return retval;
+    }
+
+    hipError_t Extract(VertexId *h_component_ids)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipStreamSynchronize(this->graph_slices[0]->stream), "CCProblem Extract sync failed");
+        if (this->nodes > 0)
+            GR_CHECK(hipMemcpy(h_component_ids, data_slices[0]->d_component_ids, sizeof(VertexId) * static_cast<size_t>(this->nodes),
+                               hipMemcpyDeviceToHost),
+                     "CCProblem hipMemcpy d_component_ids failed");
+        num_components = 0;
+        for (SizeT i = 0; i < this->nodes; ++i) num_components += (h_component_ids[i] == i);  // cc_problem.cuh:164-170
+        return retval;
+    }
+
+    // roots in increasing id order and the size of each component, O(n)
+    void ComputeCCHistogram(const VertexId *h_component_ids, VertexId *h_roots, unsigned int *h_histograms)
+    {
+        std::vector<int> slot(static_cast<size_t>(this->nodes > 0 ? this->nodes : 1), -1);
+        num_components = 0;
+        for (SizeT i = 0; i < this->nodes; ++i) {
+            if (h_component_ids[i] == i) {
+                slot[i] = static_cast<int>(num_components);
+                h_roots[num_components] = i;
+                h_histograms[num_components] = 0;
+                ++num_components;
+            }
+        }
+        for (SizeT i = 0; i < this->nodes; ++i) {
+            const int s = slot[h_component_ids[i]];
+            if (s >= 0) ++h_histograms[s];
+        }
+    }
+};
+
+}  // namespace cc
+}  // namespace app
+}  // namespace gunrock

@@ -122,6 +122,36 @@ struct FrontierWriter {
             }
         }
     }
+
+    // Flush for queues that feed a FILTER (or an edge-parallel operator) rather than an advance: only the ids are
+    // written, the tail counts entries (edge half stays 0).  Same calling rules as Flush.
+    static __device__ __forceinline__ void FlushIds(Storage &st, const int n, VertexId *d_out, SizeT capacity,
+                                                    unsigned long long *d_tail, int *d_overflow)
+    {
+        if (n == 0) return;  // uniform
+        if (threadIdx.x == 0) {
+            st.base = atomicAdd(d_tail, static_cast<unsigned long long>(n));
+            st.count = 0;
+        }
+        VertexId v[PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const int i = j * THREADS + threadIdx.x;
+            if (i < n) v[j] = st.buf[i];
+        }
+        __syncthreads();
+        const unsigned long long base = util::TailCount(st.base);
+        if (base + static_cast<unsigned long long>(n) > static_cast<unsigned long long>(capacity)) {
+            if (threadIdx.x == 0) *d_overflow = 1;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const int i = j * THREADS + threadIdx.x;
+            if (i < n) d_out[base + i] = v[j];  // coalesced
+        }
+        __syncthreads();  // st.base may be rewritten by the next flush
+    }
 };
 
 }  // namespace oprtr

@@ -26,12 +26,8 @@ void gunrock_topk_func(struct GunrockGraph *, void *, void *, void *, const stru
 
 }  // extern "C"
 
-// TEMPORARY until cc_app.hip / sssp_app.hip land (same round)
+// TEMPORARY until sssp_app.hip lands (same round)
 extern "C" {
-void gunrock_cc_func(struct GunrockGraph *, const struct GunrockGraph *, struct GunrockConfig, struct GunrockDataType)
-{
-    std::fprintf(stderr, "[gunrock-mi355x] gunrock_cc_func: not built yet.\n");
-}
 void gunrock_sssp_func(struct GunrockGraph *, void *, const struct GunrockGraph *, struct GunrockConfig,
                        struct GunrockDataType)
 {

@@ -100,6 +100,27 @@ void grx_bfs_destroy(grx_bfs *p);
 void grx_bfs_count_visited(int nodes, const int *row_offsets, const int *labels,
                            long long *nodes_visited, long long *edges_visited);
 
+/* ------------------------------------------------------------------------------------------------
+ * CC: CCProblem + CCEnactor (reference gunrock/app/cc/cc_problem.cuh:36-440, cc_enactor.cuh:36-919)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct grx_cc grx_cc;
+
+int grx_cc_create(grx_cc **out, int instrument, int device);
+/* CCProblem::Init(false, csr, 1) (reference cc_problem.cuh:221-345) */
+int grx_cc_init(grx_cc *p, int nodes, int edges, const int *row_offsets, const int *col_indices);
+int grx_cc_init_device(grx_cc *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices);
+/* CCProblem::Reset(frontier_type) (reference cc_problem.cuh:361-440) */
+int grx_cc_reset(grx_cc *p);
+/* CCEnactor::Enact(problem, max_grid_size) (reference cc_enactor.cuh:889-919), HIP-event timed */
+int grx_cc_enact(grx_cc *p, int max_grid_size, float *elapsed_ms);
+/* sweeps of the last Enact: edge sweeps (hooks) and vertex sweeps (jumps / mask updates) -- I_h and I_j of the
+ * roofline figure -- plus, when instrumented, kernel launches and their summed time */
+int grx_cc_stats(grx_cc *p, long long *edge_sweeps, long long *vertex_sweeps, long long *kernel_launches, double *kernel_ms);
+/* CCProblem::Extract(h_component_ids) (reference cc_problem.cuh:144-175); num_components = #{v: id[v] == v} */
+int grx_cc_extract(grx_cc *p, int *h_component_ids, unsigned *num_components);
+int grx_cc_device_results(grx_cc *p, int **d_component_ids);
+void grx_cc_destroy(grx_cc *p);
+
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */
 const char *grx_version(void);
 

@@ -1,0 +1,104 @@
+"""CC parity on the GPU: component ids must equal the oracle's bit for bit (both converge to the smallest vertex
+id of each component); the reference itself only compares the component COUNT (tests/cc/test_cc.cu:315-320)."""
+import os
+
+import numpy as np
+import pytest
+
+import gunrockinst_amd as ga
+from oracle import gr_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g, instrument=False):
+    p = ga.CcProblem(instrument).init(g.nodes, g.row_offsets, g.col_indices)
+    p.reset()
+    ms = p.enact()
+    ids, count = p.extract()
+    st = p.stats()
+    p.close()
+    return ids, count, st, ms
+
+
+def _check(g):
+    ids, count, st, _ = _run(g)
+    ref, ref_count = o.cc(g)
+    assert np.array_equal(ids, ref)
+    assert count == ref_count
+    assert (ids <= np.arange(g.nodes)).all()
+    return st
+
+
+def test_fixture7_known_answer(golden, capfd):
+    f = golden["fixture7"]
+    ro, ci = np.array(f["row_offsets"], np.int32), np.array(f["col_indices"], np.int32)
+    ids = ga.gunrock_cc(7, ro, ci)
+    assert ids.tolist() == [0] * 7
+    assert ids[f["ctest_cc"]["node"]] == f["ctest_cc"]["component"]          # CMakeLists.txt:223-225
+    assert "GPU Connected Component finished in" in capfd.readouterr().out
+
+
+def test_test_cc_mtx_directed_and_undirected(golden, golden_dir):
+    f = golden["test_cc"]
+    for und in (True, False):       # tests/cc loads the file directed (test_cc.cu:415); hooks see weak components
+        g = o.build_market(os.path.join(golden_dir, f["mtx"]), undirected=und)
+        ids, count, _, _ = _run(g)
+        assert ids.tolist() == f["cc_labels"] and count == 2
+
+
+def test_bips98_606_simple_example_path(golden_dir):
+    g = o.build_market(os.path.join(golden_dir, "bips98_606.mtx"), undirected=True)
+    st = _check(g)
+    _, _, ih, ij = o.cc_reference_schedule(g)
+    # same schedule family as the reference: sweep counts are of the same order (exact counts depend on race order)
+    assert 2 <= st["edge_sweeps"] <= 3 * ih + 2 and st["vertex_sweeps"] >= 3
+
+
+def test_chesapeake_and_test_pr(golden_dir):
+    for name, und in [("chesapeake.mtx", True), ("test_pr.mtx", False), ("test_bc.mtx", False)]:
+        _check(o.build_market(os.path.join(golden_dir, name), undirected=und))
+
+
+def test_edge_cases():
+    _check(o.Csr(5, [0, 0, 0, 0, 0, 0], []))                      # no edges: every vertex its own component
+    _check(o.Csr(1, [0, 0], []))
+    n = 4000                                                       # long path: deep trees, many jump rounds
+    ro = np.minimum(np.arange(n + 1), n - 1).astype(np.int32)
+    _check(o.Csr(n, ro, np.arange(1, n, dtype=np.int32)))
+    # reversed path (edges point to smaller ids) and a star with the hub as the largest id
+    ro = np.concatenate(([0], np.arange(0, n))).astype(np.int32)
+    _check(o.Csr(n, ro, np.arange(0, n - 1, dtype=np.int32)))
+    hub = 70000
+    ro = np.zeros(hub + 1, np.int32)
+    ro[-1] = hub - 1
+    _check(o.Csr(hub, ro, np.arange(0, hub - 1, dtype=np.int32)))
+
+
+@pytest.mark.parametrize("scale,ef,und", [(10, 1, True), (12, 2, False), (14, 8, True), (16, 4, True), (18, 8, True)])
+def test_rmat_parity(scale, ef, und):
+    g = o.rmat_seeded(scale, ef << scale, undirected=und)
+    _check(g)
+
+
+def test_many_small_components():
+    rng = np.random.default_rng(3)
+    n = 50000
+    rows = rng.integers(0, n, n // 2, dtype=np.int32)
+    cols = (rows + rng.integers(1, 4, n // 2, dtype=np.int32)) % n
+    g0 = ga.HostGraph.from_coo(n, rows, cols)
+    _check(o.Csr(n, g0.row_offsets.copy(), g0.col_indices.copy()))
+
+
+def test_instrumented_and_rerun():
+    g = o.rmat_seeded(14, 8 << 14)
+    p = ga.CcProblem(True).init(g.nodes, g.row_offsets, g.col_indices)
+    ref = o.cc(g)[0]
+    for _ in range(2):
+        p.reset()
+        ms = p.enact()
+        ids, _ = p.extract()
+        assert np.array_equal(ids, ref)
+    st = p.stats()
+    assert st["kernel_launches"] == st["edge_sweeps"] + st["vertex_sweeps"] and 0 < st["kernel_ms"] <= ms
+    p.close()
