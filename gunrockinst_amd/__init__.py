@@ -8,10 +8,10 @@ CPU fallback: importing the binding without the built library raises.
 from .capi import (  # noqa: F401
     GunrockConfig, GunrockDataType, GunrockGraph, LIB_PATH, lib, build_library,
     VTXID_INT, SIZET_INT, VALUE_INT, VALUE_UINT, VALUE_FLOAT, SRC_MANUALLY, SRC_RANDOMIZE, SRC_LARGEST_DEGREE,
-    HostGraph, BfsProblem, CcProblem, gunrock_bfs, gunrock_cc, version,
+    HostGraph, BfsProblem, CcProblem, SsspProblem, gunrock_bfs, gunrock_cc, gunrock_sssp, version,
 )
 
 __all__ = [
     "GunrockConfig", "GunrockDataType", "GunrockGraph", "LIB_PATH", "lib", "build_library",
-    "HostGraph", "BfsProblem", "CcProblem", "gunrock_bfs", "gunrock_cc", "version",
+    "HostGraph", "BfsProblem", "CcProblem", "SsspProblem", "gunrock_bfs", "gunrock_cc", "gunrock_sssp", "version",
 ]

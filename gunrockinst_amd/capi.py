@@ -102,6 +102,15 @@ _SIGNATURES = {
     "grx_cc_extract": (C.c_int, [C.c_void_p, i32p, C.POINTER(C.c_uint)]),
     "grx_cc_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "grx_cc_destroy": (None, [C.c_void_p]),
+    "grx_sssp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "grx_sssp_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p, C.POINTER(C.c_uint32), C.c_int]),
+    "grx_sssp_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "grx_sssp_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "grx_sssp_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "grx_sssp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_float)]),
+    "grx_sssp_extract": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), i32p]),
+    "grx_sssp_destroy": (None, [C.c_void_p]),
     "grx_bfs_count_visited": (None, [C.c_int, i32p, i32p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "grx_version": (C.c_char_p, []),
 }
@@ -409,3 +418,79 @@ def gunrock_cc(nodes, row_offsets, col_indices, device=0):
     dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
     lib().gunrock_cc_func(C.byref(gout), C.byref(gin), cfg, dt)
     return _take_node_values(gout, nodes, np.int32)
+
+
+class SsspProblem:
+    """SSSPProblem + SSSPEnactor behind the handle C ABI."""
+
+    def __init__(self, mark_pred=False, instrument=False, device=0):
+        self._h = C.c_void_p()
+        self.mark_pred = bool(mark_pred)
+        _check(lib().grx_sssp_create(C.byref(self._h), int(mark_pred), int(instrument), device), "grx_sssp_create")
+        self.nodes = 0
+
+    def init(self, nodes, row_offsets, col_indices, weights, delta_factor=16):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.uint32)
+        self.nodes = int(nodes)
+        _check(lib().grx_sssp_init(self._h, nodes, ci.shape[0], _p(ro), _p(ci), w.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   delta_factor), "SSSPProblem::Init")
+        return self
+
+    def init_device(self, nodes, edges, d_row_offsets, d_col_indices, d_weights, delta):
+        self.nodes = int(nodes)
+        _check(lib().grx_sssp_init_device(self._h, nodes, edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices),
+                                          C.c_void_p(d_weights), float(delta)), "SSSPProblem::Init(device)")
+        return self
+
+    def reset(self, src, queue_sizing=1.0):
+        _check(lib().grx_sssp_reset(self._h, int(src), float(queue_sizing)), "SSSPProblem::Reset")
+
+    def enact(self, src, max_grid_size=0):
+        ms = C.c_float()
+        _check(lib().grx_sssp_enact(self._h, int(src), max_grid_size, C.byref(ms)), "SSSPEnactor::Enact")
+        return float(ms.value)
+
+    def stats(self):
+        v, e, it, l = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+        k, d = C.c_double(), C.c_float()
+        _check(lib().grx_sssp_stats(self._h, C.byref(v), C.byref(e), C.byref(it), C.byref(l), C.byref(k), C.byref(d)),
+               "grx_sssp_stats")
+        return {"relaxed_vertices": v.value, "relaxed_edges": e.value, "iterations": it.value,
+                "kernel_launches": l.value, "kernel_ms": k.value, "delta": d.value}
+
+    def extract(self):
+        dist = np.empty(max(self.nodes, 1), dtype=np.uint32)
+        preds = np.empty(max(self.nodes, 1), dtype=np.int32) if self.mark_pred else None
+        _check(lib().grx_sssp_extract(self._h, dist.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      None if preds is None else _p(preds)), "SSSPProblem::Extract")
+        return dist[:self.nodes], (None if preds is None else preds[:self.nodes])
+
+    def close(self):
+        if self._h:
+            lib().grx_sssp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gunrock_sssp(nodes, row_offsets, col_indices, weights, src=0, mark_pred=True, delta_factor=16, queue_size=1.0,
+                 src_mode=SRC_MANUALLY, device=0):
+    """Call gunrock_sssp_func as reference shared_lib_tests/test_sssp.c does; returns (distances, predecessors)."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    w = np.ascontiguousarray(weights, dtype=np.uint32)
+    gin = _graph_struct(nodes, ro, ci, w)
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.mark_pred, cfg.src_node, cfg.device = mark_pred, src, device
+    cfg.delta_factor, cfg.queue_size, cfg.src_mode = delta_factor, queue_size, src_mode
+    preds = np.empty(max(nodes, 1), dtype=np.int32)
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_UINT)
+    lib().gunrock_sssp_func(C.byref(gout), preds.ctypes.data_as(C.c_void_p), C.byref(gin), cfg, dt)
+    return _take_node_values(gout, nodes, np.uint32), preds[:nodes]

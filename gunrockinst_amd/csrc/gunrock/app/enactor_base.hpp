@@ -11,6 +11,7 @@
 
 #include <vector>
 
+#include <gunrock/app/problem_base.hpp>
 #include <gunrock/util/error_utils.hpp>
 #include <gunrock/util/frontier.hpp>
 

@@ -78,7 +78,9 @@ struct AdvanceArgs {
     int *d_overflow;
 };
 
-template <typename KernelPolicy, typename ProblemData, typename Functor>
+// OUT_WITH_DEGREES: the output is a full frontier (vertex, row start, degree prefix) ready for the next advance
+// (BFS); false = ids only, for outputs that pass through a filter / priority-queue split first (SSSP).
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
 __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a,
     typename ProblemData::DataSlice slice)
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
             if (here < THREADS) break;  // uniform: slice ended inside this round
         }
         if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
-            Writer::template Flush<true>(s_writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+            if (OUT_WITH_DEGREES) Writer::template Flush<true>(s_writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+            else Writer::FlushIds(s_writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
         }
 
         // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
@@ -227,12 +230,13 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     // final flush (barrier above: all appends complete, count is stable)
     const int rest = Writer::Count(s_writer);
     __syncthreads();
-    Writer::template Flush<true>(s_writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+    if (OUT_WITH_DEGREES) Writer::template Flush<true>(s_writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+    else Writer::FlushIds(s_writer, rest, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
 }
 
 // Host-side launch.  Mirrors advance::LaunchKernel (advance/kernel.cuh:101-129) at the distilled level of
 // input/output frontier, graph, problem data, traversal type.
-template <typename KernelPolicy, typename ProblemData, typename Functor>
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
 hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
                         const typename ProblemData::DataSlice &slice, int max_grid_size, hipStream_t stream,
                         TYPE /*ADVANCE_TYPE: only V2V is on the BFS/SSSP path*/ = V2V)
@@ -241,7 +245,7 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
     const long long tiles = (static_cast<long long>(args.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
     long long grid = tiles < max_grid_size ? tiles : max_grid_size;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor>), dim3(static_cast<unsigned>(grid)),
+    hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>), dim3(static_cast<unsigned>(grid)),
                        dim3(KernelPolicy::THREADS), 0, stream, args, slice);
     return util::GRError("advance::LoadBalancedKernel launch failed", __FILE__, __LINE__);
 }

@@ -25,12 +25,3 @@ void gunrock_topk_func(struct GunrockGraph *, void *, void *, void *, const stru
 }
 
 }  // extern "C"
-
-// TEMPORARY until sssp_app.hip lands (same round)
-extern "C" {
-void gunrock_sssp_func(struct GunrockGraph *, void *, const struct GunrockGraph *, struct GunrockConfig,
-                       struct GunrockDataType)
-{
-    std::fprintf(stderr, "[gunrock-mi355x] gunrock_sssp_func: not built yet.\n");
-}
-}

@@ -121,6 +121,32 @@ int grx_cc_extract(grx_cc *p, int *h_component_ids, unsigned *num_components);
 int grx_cc_device_results(grx_cc *p, int **d_component_ids);
 void grx_cc_destroy(grx_cc *p);
 
+/* ------------------------------------------------------------------------------------------------
+ * SSSP: SSSPProblem + SSSPEnactor (reference gunrock/app/sssp/sssp_problem.cuh:35-387, sssp_enactor.cuh:36-563)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct grx_sssp grx_sssp;
+
+/* mark_pred selects SSSPProblem<..., MARK_PATHS = true> (reference tests/sssp/test_sssp.cu:588-633) */
+int grx_sssp_create(grx_sssp **out, int mark_pred, int instrument, int device);
+/* SSSPProblem::Init(false, csr, 1, delta_factor) (reference sssp_problem.cuh:185-288); weights are unsigned 32-bit */
+int grx_sssp_init(grx_sssp *p, int nodes, int edges, const int *row_offsets, const int *col_indices,
+                  const unsigned *edge_weights, int delta_factor);
+/* CSR + weights already in HBM (borrowed); `delta` is the bucket width to use (0 = one bucket per distance) */
+int grx_sssp_init_device(grx_sssp *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices,
+                         const unsigned *d_edge_weights, float delta);
+/* SSSPProblem::Reset(src, frontier_type, queue_sizing) (reference sssp_problem.cuh:299-377) */
+int grx_sssp_reset(grx_sssp *p, int src, double queue_sizing);
+/* SSSPEnactor::Enact(context, problem, src, queue_sizing, max_grid_size) (reference sssp_enactor.cuh:485-563) */
+int grx_sssp_enact(grx_sssp *p, int src, int max_grid_size, float *elapsed_ms);
+/* work done by the last Enact: vertices dequeued, edge slots relaxed, BSP iterations; instrumented: kernel launches
+ * and summed kernel time; the bucket width in use */
+int grx_sssp_stats(grx_sssp *p, long long *relaxed_vertices, long long *relaxed_edges, long long *iterations,
+                   long long *kernel_launches, double *kernel_ms, float *delta);
+/* SSSPProblem::Extract(h_labels, h_preds): unsigned distances (UINT_MAX unreachable); preds = own id for the source and
+ * unreached vertices (reference iota initialisation, sssp_problem.cuh:363-372); h_preds may be NULL */
+int grx_sssp_extract(grx_sssp *p, unsigned *h_distances, int *h_preds);
+void grx_sssp_destroy(grx_sssp *p);
+
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */
 const char *grx_version(void);
 
