@@ -111,6 +111,18 @@ _SIGNATURES = {
                                  C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "grx_sssp_extract": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), i32p]),
     "grx_sssp_destroy": (None, [C.c_void_p]),
+    "grx_pbfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "grx_pbfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_pbfs_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "grx_pbfs_frontier": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "grx_pbfs_advance_local": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
+    "grx_pbfs_filter_received": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "grx_pbfs_queue_to_bitmap": (C.c_int, [C.c_void_p]),
+    "grx_pbfs_frontier_bitmap": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "grx_pbfs_bottom_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "grx_pbfs_bitmap_to_queue": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "grx_pbfs_labels": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_pbfs_destroy": (None, [C.c_void_p]),
     "grx_bfs_count_visited": (None, [C.c_int, i32p, i32p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "grx_version": (C.c_char_p, []),
 }

@@ -142,7 +142,7 @@ class BFSEnactor : public EnactorBase {
                 bargs.nodes = problem->nodes;
                 bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
                 bargs.d_inv_column_indices = ds->d_inv_column_indices;
-                bargs.d_frontier_in = ds->d_frontier_mask[cur_mask];
+                oprtr::advance::BitmapLookup<VertexId> lookup{ds->d_frontier_mask[cur_mask]};
                 bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[cur_mask ^ 1]);
                 bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
                 bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
@@ -152,8 +152,8 @@ class BFSEnactor : public EnactorBase {
                 const long long cap = max_grid_size > 0 ? max_grid_size : cu_count * 8;
                 if (grid > cap) grid = cap;
                 if (grid < 1) grid = 1;
-                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem>),
-                                   dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds);
+                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
+                                   dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
                 if ((retval = util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__))) break;
                 cur_mask ^= 1;
             } else {

@@ -40,21 +40,45 @@ __global__ void QueueToBitmapKernel(const VertexId *d_queue, SizeT length, unsig
     }
 }
 
+// Frontier membership tests for the bottom-up sweep.
+// BitmapLookup: one bitmap indexed by vertex id (single GPU).
+// StripedBitmapLookup: vertex-cut over P ranks, owner = v mod P, local id = v div P (the reference's only multi-GPU
+// vestige, problem_base.cuh:185-210); the all-gathered bitmaps of the P ranks sit back to back, words_per_rank apart.
+template <typename VertexId>
+struct BitmapLookup {
+    const unsigned *bits;
+    __device__ __forceinline__ bool operator()(VertexId u) const
+    {
+        return (bits[static_cast<unsigned>(u) >> 5] >> (u & 31)) & 1u;
+    }
+};
+template <typename VertexId>
+struct StripedBitmapLookup {
+    const unsigned *bits;
+    unsigned parts;
+    unsigned words_per_rank;
+    __device__ __forceinline__ bool operator()(VertexId u) const
+    {
+        const unsigned owner = static_cast<unsigned>(u) % parts, local = static_cast<unsigned>(u) / parts;
+        return (bits[owner * words_per_rank + (local >> 5)] >> (local & 31)) & 1u;
+    }
+};
+
 template <typename VertexId, typename SizeT>
 struct BottomUpArgs {
     SizeT nodes;
     const SizeT *d_inv_row_offsets;
     const VertexId *d_inv_column_indices;
-    const unsigned *d_frontier_in;          // current frontier bitmap (read only)
     unsigned long long *d_frontier_out;     // next frontier bitmap, every word is written
     unsigned long long *d_visited;          // visited bitmap, owner-updated
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
 };
 
-template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData>
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
 __global__ __launch_bounds__(THREADS) void BottomUpKernel(
-    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice)
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
@@ -91,16 +115,16 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
             for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
                 if (__ballot(open && parent < 0 && pos < end) == 0) break;  // wave-uniform
                 VertexId nb[PROBE];
-                unsigned fw[PROBE];
+                bool fw[PROBE];
 #pragma unroll
                 for (int j = 0; j < PROBE; ++j)
                     nb[j] = (open && parent < 0 && pos + j < end) ? a.d_inv_column_indices[pos + j] : static_cast<VertexId>(-1);
 #pragma unroll
                 for (int j = 0; j < PROBE; ++j)
-                    fw[j] = (nb[j] >= 0) ? a.d_frontier_in[static_cast<unsigned>(nb[j]) >> 5] : 0u;
+                    fw[j] = (nb[j] >= 0) ? in_frontier(nb[j]) : false;
 #pragma unroll
                 for (int j = 0; j < PROBE; ++j)
-                    if (parent < 0 && nb[j] >= 0 && ((fw[j] >> (nb[j] & 31)) & 1u)) parent = nb[j];
+                    if (parent < 0 && fw[j]) parent = nb[j];
                 pos += PROBE;
             }
 
@@ -116,7 +140,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                     VertexId u = -1;
                     if (mine < e) u = a.d_inv_column_indices[mine];
                     bool hit = false;
-                    if (u >= 0) hit = (a.d_frontier_in[static_cast<unsigned>(u) >> 5] >> (u & 31)) & 1u;
+                    if (u >= 0) hit = in_frontier(u);
                     const unsigned long long hm = __ballot(hit);
                     if (hm) {
                         hit_parent = __shfl(u, __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);

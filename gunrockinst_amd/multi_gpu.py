@@ -1,0 +1,369 @@
+"""Vertex-partitioned multi-GPU BFS: one process per GPU, collectives over torch.distributed (RCCL on xGMI).
+
+The reference is single-GPU (gunrock/app/problem_base.cuh:336-338 is a TODO).  This layer keeps its striped
+ownership rule -- owner = v mod P, local id = v div P (problem_base.cuh:185-210) -- and adds the per-level exchange:
+
+  top-down level : local advance -> ids bucketed by owner -> all_to_all_single(counts) + all_to_all_single(ids)
+                   -> local filter (claim, label, next frontier)
+  bottom-up level: all_gather of the per-rank frontier bitmaps (n/8 bytes in total) -> local bottom-up sweep
+  every level    : one all_reduce of (frontier vertices, frontier edges) for termination and direction choice
+
+xGMI is point-to-point: the all-to-all keeps all 7 links of a GPU busy at once, and the dense levels of an R-MAT
+search move only bitmaps (2 MiB per level at scale-24), never ids.
+
+Compute never happens here: `engine` performs the local steps.  HipEngine drives the HIP kernels through the C ABI
+(grx_pbfs_*).  The level loop is engine-agnostic so CPU tests can run it over gloo with a numpy test double.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ownership rule (reference problem_base.cuh:185-210)
+# ------------------------------------------------------------------------------------------------------------------
+def owner_of(v, parts):
+    return v % parts
+
+
+def local_id(v, parts):
+    return v // parts
+
+
+def local_count(n_global, parts, rank):
+    return (n_global - rank + parts - 1) // parts if n_global > rank else 0
+
+
+def mask_words(n):
+    return ((n + 63) // 64) * 2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# collectives (device tensors on RCCL; staged through the host when the backend is gloo)
+# ------------------------------------------------------------------------------------------------------------------
+class Comm:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.host_staged = self.backend == "gloo"
+
+    def _stage(self, t):
+        return t.cpu() if (self.host_staged and t.is_cuda) else t
+
+    def all_reduce_sum(self, values):
+        t = torch.tensor(values, dtype=torch.int64)
+        if not self.host_staged:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(x) for x in t.tolist()]
+
+    def all_reduce_max(self, values):
+        t = torch.tensor(values, dtype=torch.int64)
+        if not self.host_staged:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [int(x) for x in t.tolist()]
+
+    def exchange_counts(self, send_counts):
+        s = torch.tensor(send_counts, dtype=torch.int64)
+        if not self.host_staged:
+            s = s.cuda()
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return [int(x) for x in r.tolist()]
+
+    def all_to_all_v(self, send, send_counts, recv_counts):
+        """send: int32 tensor, segments in rank order.  Returns the received int32 tensor on send's device."""
+        dev = send.device
+        s = self._stage(send)
+        r = torch.empty(int(sum(recv_counts)), dtype=torch.int32, device=s.device)
+        dist.all_to_all_single(r, s, list(recv_counts), list(send_counts), group=self.group)
+        return r.to(dev) if r.device != dev else r
+
+    def all_gather(self, t):
+        dev = t.device
+        s = self._stage(t)
+        out = torch.empty(self.world * s.numel(), dtype=s.dtype, device=s.device)
+        dist.all_gather_into_tensor(out, s, group=self.group)
+        return out.to(dev) if out.device != dev else out
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the level loop (engine-agnostic)
+# ------------------------------------------------------------------------------------------------------------------
+class PartitionedBfs:
+    """engine must provide: reset(src)->(len, edges); advance_local()->(send_counts, send_tensor);
+    filter_received(recv_tensor)->(len, edges); queue_to_bitmap(); frontier_bitmap()->int32 tensor;
+    bottom_up(gathered_tensor, words_per_rank)->(len, edges); bitmap_to_queue()->(len, edges)."""
+
+    def __init__(self, engine, comm, n_global, m_global, alpha=14.0, beta=24.0):
+        self.engine, self.comm = engine, comm
+        self.n_global, self.m_global = int(n_global), int(m_global)
+        self.alpha, self.beta = float(alpha), float(beta)
+        self.trace = []
+
+    def run(self, src, direction_optimizing=True):
+        eng, comm = self.engine, self.comm
+        self.trace = []
+        glen, gedges = comm.all_reduce_sum(list(eng.reset(src)))
+        unexplored = self.m_global
+        bottom_up = False
+        levels = 0
+        while glen > 0:
+            if direction_optimizing and not bottom_up and gedges * self.alpha > unexplored:
+                eng.queue_to_bitmap()
+                bottom_up = True
+            elif direction_optimizing and bottom_up and glen * self.beta < self.n_global:
+                glen, gedges = comm.all_reduce_sum(list(eng.bitmap_to_queue()))
+                bottom_up = False
+                if glen == 0:
+                    break
+            unexplored -= gedges
+            if bottom_up:
+                bitmap = eng.frontier_bitmap()
+                gathered = comm.all_gather(bitmap)
+                l, e = eng.bottom_up(gathered, bitmap.numel())
+            else:
+                send_counts, send = eng.advance_local()
+                recv_counts = comm.exchange_counts(send_counts)
+                recv = comm.all_to_all_v(send, send_counts, recv_counts)
+                l, e = eng.filter_received(recv)
+            self.trace.append(("bottom-up" if bottom_up else "top-down", glen, gedges))
+            glen, gedges = comm.all_reduce_sum([l, e])
+            levels += 1
+        return levels
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HIP engine (C ABI)
+# ------------------------------------------------------------------------------------------------------------------
+class HipEngine:
+    def __init__(self, n_global, parts, rank, d_row_offsets, d_col_indices, device_index=0):
+        from . import capi, devgraph
+        self._capi, self._dg = capi, devgraph
+        self.lib = capi.lib()
+        self.n_global, self.parts, self.rank = n_global, parts, rank
+        self.ro, self.ci = d_row_offsets, d_col_indices          # torch int32 tensors (kept alive here)
+        self.n_local = int(d_row_offsets.shape[0]) - 1
+        self.m_local = int(d_col_indices.shape[0])
+        self._h = C.c_void_p()
+        self._check(self.lib.grx_pbfs_create(C.byref(self._h), device_index), "grx_pbfs_create")
+        self._check(self.lib.grx_pbfs_init_device(self._h, n_global, parts, rank, self.n_local, self.m_local,
+                                                  C.c_void_p(d_row_offsets.data_ptr()),
+                                                  C.c_void_p(d_col_indices.data_ptr())), "grx_pbfs_init_device")
+        self._counts = (C.c_uint32 * 64)()
+        self.device = d_row_offsets.device
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError("gunrockinst_amd: %s failed (code %d)" % (what, rc))
+
+    def _pair(self, fn, *args):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(fn(self._h, *args, C.byref(a), C.byref(b)), fn.__name__)
+        return int(a.value), int(b.value)
+
+    def reset(self, src):
+        self._check(self.lib.grx_pbfs_reset(self._h, int(src)), "grx_pbfs_reset")
+        return self._pair(self.lib.grx_pbfs_frontier)
+
+    def advance_local(self):
+        buf = C.c_void_p()
+        self._check(self.lib.grx_pbfs_advance_local(self._h, self._counts, C.byref(buf)), "grx_pbfs_advance_local")
+        counts = [int(self._counts[i]) for i in range(self.parts)]
+        return counts, self._dg.as_tensor(buf.value, sum(counts), device=self.device)
+
+    def filter_received(self, recv):
+        recv = recv.contiguous()
+        self._keep = recv
+        return self._pair(self.lib.grx_pbfs_filter_received, C.c_void_p(recv.data_ptr() if recv.numel() else None),
+                          int(recv.numel()))
+
+    def queue_to_bitmap(self):
+        self._check(self.lib.grx_pbfs_queue_to_bitmap(self._h), "grx_pbfs_queue_to_bitmap")
+
+    def frontier_bitmap(self):
+        ptr, words = C.c_void_p(), C.c_int()
+        self._check(self.lib.grx_pbfs_frontier_bitmap(self._h, C.byref(ptr), C.byref(words)), "grx_pbfs_frontier_bitmap")
+        return self._dg.as_tensor(ptr.value, words.value, device=self.device)
+
+    def bottom_up(self, gathered, words_per_rank):
+        gathered = gathered.contiguous()
+        self._keep = gathered
+        return self._pair(self.lib.grx_pbfs_bottom_up, C.c_void_p(gathered.data_ptr()), int(words_per_rank))
+
+    def bitmap_to_queue(self):
+        return self._pair(self.lib.grx_pbfs_bitmap_to_queue)
+
+    def labels_tensor(self):
+        ptr = C.c_void_p()
+        self._check(self.lib.grx_pbfs_labels(self._h, C.byref(ptr)), "grx_pbfs_labels")
+        return self._dg.as_tensor(ptr.value, self.n_local, device=self.device)
+
+    def labels(self):
+        return self.labels_tensor().cpu().numpy()
+
+    def close(self):
+        if self._h:
+            self.lib.grx_pbfs_destroy(self._h)
+            self._h = None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# partitioned graph construction on the device
+# ------------------------------------------------------------------------------------------------------------------
+def partition_rmat_device(scale, edge_factor, seed, rank, parts, chunk_pairs=1 << 26, device="cuda"):
+    """Each rank generates the whole seeded tuple stream in chunks, keeps the directed tuples whose SOURCE it owns and
+    builds its local CSR (local row ids, global column ids) with Csr::FromCoo's graph semantics."""
+    from . import devgraph
+    n = 1 << scale
+    pairs = edge_factor << scale
+    kept = []
+    for first in range(0, pairs, chunk_pairs):
+        cnt = min(chunk_pairs, pairs - first)
+        rows, cols = devgraph.rmat_tuples_device(scale, cnt, seed, first=first, device=device)
+        r = torch.cat([rows, cols]).long()
+        c = torch.cat([cols, rows]).long()
+        del rows, cols
+        m = (r != c) & ((r % parts) == rank)
+        kept.append(((r[m] // parts) << 32) | c[m])
+        del r, c, m
+    keys = torch.unique(torch.cat(kept))
+    del kept
+    n_local = local_count(n, parts, rank)
+    src = keys >> 32
+    ci = (keys & 0xFFFFFFFF).int().contiguous()
+    del keys
+    counts = torch.bincount(src, minlength=n_local)
+    ro = torch.zeros(n_local + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=ro[1:])
+    return ro.int().contiguous(), ci
+
+
+def partition_csr_host(row_offsets, col_indices, rank, parts):
+    """Split a host CSR (numpy) by the striped rule; used by tests on small graphs."""
+    n = row_offsets.shape[0] - 1
+    mine = np.arange(rank, n, parts)
+    deg = (row_offsets[1:] - row_offsets[:-1])[mine]
+    ro = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
+    idx = np.concatenate([np.arange(row_offsets[v], row_offsets[v + 1]) for v in mine]) if mine.size and deg.sum() else \
+        np.empty(0, np.int64)
+    return ro, col_indices[idx.astype(np.int64)].astype(np.int32)
+
+
+def assemble_labels(comm, local_labels, n_global):
+    """Gather owner-striped labels to every rank (Extract for the partitioned problem)."""
+    parts = comm.world
+    n_max = (n_global + parts - 1) // parts
+    pad = torch.full((n_max,), -2, dtype=torch.int32)
+    pad[:local_labels.shape[0]] = torch.as_tensor(local_labels, dtype=torch.int32)
+    if not comm.host_staged:
+        pad = pad.cuda()
+    out = torch.empty(parts * n_max, dtype=torch.int32, device=pad.device)
+    dist.all_gather_into_tensor(out, pad, group=comm.group)
+    out = out.cpu().numpy().reshape(parts, n_max)
+    full = np.empty(n_global, dtype=np.int32)
+    for r in range(parts):
+        full[r::parts] = out[r, :local_count(n_global, parts, r)]
+    return full
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bench leg for N > 1 (called by bench.py under torch.distributed.run)
+# ------------------------------------------------------------------------------------------------------------------
+def bench(args, rank, world, local_rank):
+    from . import devgraph
+    comm = Comm()
+    n = 1 << args.scale
+    t0 = time.time()
+    ro, ci = partition_rmat_device(args.scale, args.edge_factor, args.seed, rank, world)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    deg = (ro[1:] - ro[:-1]).long()
+    m_local = int(ci.shape[0])
+    (m_global,) = comm.all_reduce_sum([m_local])
+
+    # sources: first vertex of maximal degree + 64 seeded vertices with degree > 0 (same rule as the 1-GPU leg)
+    local_max = int(deg.max()) if deg.numel() else 0
+    (gmax,) = comm.all_reduce_max([local_max])
+    cand = torch.nonzero(deg == gmax)
+    first_local = int(cand[0]) * world + rank if cand.numel() else n
+    (neg_src0,) = comm.all_reduce_max([-first_local])
+    src0 = -neg_src0
+    picks, x = [], args.seed
+    while len(picks) < 4096:
+        x = devgraph._splitmix64(x)
+        picks.append(x % n)
+    mine = [int(deg[v // world]) if v % world == rank else 0 for v in picks]
+    degs = comm.all_reduce_sum(mine)
+    sources = [src0] + [v for v, d in zip(picks, degs) if d > 0][:64]
+
+    eng = HipEngine(n, world, rank, ro, ci, local_rank)
+    bfs = PartitionedBfs(eng, comm, n, m_global)
+
+    for k in range(args.warmup):
+        bfs.run(sources[k % len(sources)])
+    torch.cuda.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        bfs.run(sources[k % len(sources)])
+    torch.cuda.synchronize()
+    comm.barrier()
+    wall = time.perf_counter() - t0
+    (wall_us,) = comm.all_reduce_max([int(wall * 1e6)])
+    wall = wall_us / 1e6
+
+    used = [sources[k % len(sources)] for k in range(args.steps)]
+    per_src = {}
+    labels_t = eng.labels_tensor()
+    for s in sorted(set(used)):
+        depth = bfs.run(s)
+        vis = labels_t > -1
+        nv, ev = comm.all_reduce_sum([int(vis.sum()), int(deg[vis].sum())])
+        per_src[s] = (nv, ev, depth)
+    edges_total = sum(per_src[s][1] for s in used)
+    nodes_total = sum(per_src[s][0] for s in used)
+
+    # parity: rank 0 runs the single-GPU engine on the whole graph for the first source and compares all labels
+    bfs.run(sources[0])
+    full = assemble_labels(comm, eng.labels(), n)
+    parity = None
+    if rank == 0:
+        import gunrockinst_amd as ga
+        gro, gci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+        p = ga.BfsProblem(False, True, False, local_rank).init_device(n, int(gci.shape[0]), gro.data_ptr(), gci.data_ptr())
+        p.set_inverse_graph()
+        p.reset(sources[0])
+        p.enact(sources[0], traversal_mode=2)
+        single, _ = p.extract()
+        p.close()
+        parity = bool((single == full).all()) and int(gci.shape[0]) == m_global
+    eng.close()
+
+    balg = 4.0 * edges_total + 20.0 * nodes_total
+    return {
+        "metric": "MTEPS (million traversed edges/sec) BFS R-MAT scale-%d" % args.scale,
+        "value": round(edges_total / (wall * 1e6), 2), "unit": "MTEPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BFS direction-optimizing, R-MAT scale-%d (%d pairs/vertex mirrored, seed 0x%x) "
+                               "vertex-partitioned over %d GPUs (owner = v mod %d), RCCL all-to-all / all-gather per level: "
+                               "n=%d, m=%d" % (args.scale, args.edge_factor, args.seed, world, world, n, m_global),
+                   "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend},
+        "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
+        "parity_vs_single_gpu": parity,
+        "roofline": {"bound": "hbm", "achieved": round(balg / wall / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
+                     "frac": round(balg / wall / 1e9 / (8000.0 * world), 5), "traffic": None,
+                     "note": "whole-step wall time (kernels + collectives), all ranks"},
+        "cpu_baseline": None,
+    }

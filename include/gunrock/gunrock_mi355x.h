@@ -147,6 +147,41 @@ int grx_sssp_stats(grx_sssp *p, long long *relaxed_vertices, long long *relaxed_
 int grx_sssp_extract(grx_sssp *p, unsigned *h_distances, int *h_preds);
 void grx_sssp_destroy(grx_sssp *p);
 
+/* ------------------------------------------------------------------------------------------------
+ * Vertex-partitioned multi-GPU BFS: the LOCAL (one GPU, one rank) steps.  The reference has no multi-GPU code
+ * (gunrock/app/problem_base.cuh:336-338 is a TODO); ownership follows its striped rule owner = v mod parts,
+ * local id = v div parts (problem_base.cuh:185-210).  Collectives are the caller's job (RCCL via torch.distributed in
+ * gunrockinst_amd/multi_gpu.py); none of these calls communicates.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct grx_pbfs grx_pbfs;
+
+int grx_pbfs_create(grx_pbfs **out, int device);
+/* local CSR in HBM (borrowed): rows = owned vertices in local-id order, column ids GLOBAL */
+int grx_pbfs_init_device(grx_pbfs *p, int n_global, int parts, int rank, int n_local, int m_local,
+                         int *d_row_offsets, int *d_col_indices);
+/* labels = -1, bitmaps = 0; the owner of `src` seeds its frontier (BFSProblem::Reset role, bfs_problem.cuh:272-360) */
+int grx_pbfs_reset(grx_pbfs *p, int src);
+/* current local frontier: vertices with out-edges and the sum of their degrees */
+int grx_pbfs_frontier(grx_pbfs *p, unsigned *len, unsigned *edges);
+/* top-down, before the exchange: advance over the local frontier; every destination not forwarded before by this rank
+ * is bucketed by owner.  h_send_counts[parts] = ids per destination rank; *d_send_buffer = the ids as LOCAL ids of their
+ * owner, segments in rank order (what all_to_all_single wants). */
+int grx_pbfs_advance_local(grx_pbfs *p, unsigned *h_send_counts, int **d_send_buffer);
+/* top-down, after the exchange: the filter operator claims + labels the received local ids (first arrival wins) and
+ * builds the next local frontier; returns its length / edge count */
+int grx_pbfs_filter_received(grx_pbfs *p, const int *d_recv, int n_recv, unsigned *next_len, unsigned *next_edges);
+/* direction-optimizing: local queue -> local frontier bitmap (entering bottom-up) */
+int grx_pbfs_queue_to_bitmap(grx_pbfs *p);
+/* the local frontier bitmap to all-gather: `words` 32-bit words, identical on every rank */
+int grx_pbfs_frontier_bitmap(grx_pbfs *p, unsigned **d_bitmap, int *words);
+/* bottom-up level over the owned unvisited vertices against the all-gathered bitmaps (parts x words_per_rank words) */
+int grx_pbfs_bottom_up(grx_pbfs *p, const unsigned *d_gathered, int words_per_rank, unsigned *found, unsigned *found_edges);
+/* local frontier bitmap -> local queue (leaving bottom-up) */
+int grx_pbfs_bitmap_to_queue(grx_pbfs *p, unsigned *len, unsigned *edges);
+/* device pointer to the local labels (depth per owned vertex, local-id order, -1 unreached) */
+int grx_pbfs_labels(grx_pbfs *p, int **d_labels);
+void grx_pbfs_destroy(grx_pbfs *p);
+
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */
 const char *grx_version(void);
 
