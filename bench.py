@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6772)
     ap.add_argument("--cpu-baseline-runs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal-mode", type=int, default=2,
+                    help="0 = load-balanced top-down only, 2 = direction-optimizing (default)")
     return ap.parse_args()
 
 
@@ -49,9 +51,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    # GUNROCK_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the default is RCCL.
+    backend = os.environ.get("GUNROCK_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import gunrockinst_amd as ga
     from gunrockinst_amd import devgraph
@@ -80,15 +88,17 @@ def bench_single(args, torch, ga, devgraph, device_index):
     sources = [src0] + devgraph.seeded_sources(ro, 64, args.seed)
     deg = (ro[1:] - ro[:-1]).long()
 
+    mode = args.traversal_mode
     prob = ga.BfsProblem(mark_pred=False, idempotence=True, instrument=False, device=device_index)
     prob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    prob.set_inverse_graph()          # the R-MAT graph is mirrored: its CSR is its own inverse
     d_labels, _ = prob.device_results()
     labels_t = devgraph.as_tensor(d_labels, n)
 
-    def step(p, k):
+    def step(p, k, md=mode):
         s = sources[k % len(sources)]
         p.reset(s)
-        return p.enact(s)
+        return p.enact(s, traversal_mode=md)
 
     for k in range(args.warmup):
         step(prob, k)
@@ -105,7 +115,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     per_src = {}
     for s in sorted(set(used)):
         prob.reset(s)
-        prob.enact(s)
+        prob.enact(s, traversal_mode=mode)
         vis = labels_t > -1
         per_src[s] = (int(vis.sum()), int(deg[vis].sum()), prob.stats()["search_depth"])
     edges_total = sum(per_src[s][1] for s in used)
@@ -113,29 +123,48 @@ def bench_single(args, torch, ga, devgraph, device_index):
     value = edges_total / (wall * 1e6)
     enact_mteps = edges_total / (enact_ms * 1e3)
 
-    # instrumented pass for the roofline of the dominant kernel (advance::LoadBalancedKernel)
+    # secondary figure: the same sources with the load-balanced top-down advance only (reference traversal_mode 0)
+    td_ms, td_edges = 0.0, 0
+    for k in range(min(args.steps, 8)):
+        td_ms += step(prob, k, 0)
+        td_edges += per_src[sources[k % len(sources)]][1] if sources[k % len(sources)] in per_src else 0
+    topdown_mteps = td_edges / (td_ms * 1e3) if td_ms > 0 and td_edges else None
+
+    # instrumented pass (separate enactor instantiation): HIP events around every operator launch, on the launch stream
     iprob = ga.BfsProblem(False, True, instrument=True, device=device_index)
     iprob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    iprob.set_inverse_graph()
+    names = {0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel", 2: "frontier conversion"}
+    by_kind = {}
     kernel_ms, launches, balg = 0.0, 0, 0.0
     for k in range(min(args.steps, len(sources))):
         s = sources[k % len(sources)]
         iprob.reset(s)
-        iprob.enact(s)
-        st = iprob.stats()
-        kernel_ms += st["kernel_ms"]
-        launches += st["kernel_launches"]
-        nv, ev, _ = per_src.get(s) or (0, 0, 0)
-        if s not in per_src:
+        iprob.enact(s, traversal_mode=mode)
+        for rec in iprob.level_trace():
+            agg = by_kind.setdefault(rec["kind"], [0, 0.0])
+            agg[0] += 1
+            agg[1] += rec["ms"]
+            kernel_ms += rec["ms"]
+            launches += 1
+        if s in per_src:
+            nv, ev, _ = per_src[s]
+        else:
             il, _ = iprob.device_results()
             vis = devgraph.as_tensor(il, n) > -1
             nv, ev = int(vis.sum()), int(deg[vis].sum())
         balg += 4.0 * ev + 20.0 * nv
-    achieved = balg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # GB/s
+    dom = max(by_kind, key=lambda kd: by_kind[kd][1]) if by_kind else 0
+    achieved = balg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # GB/s over all operator launches of a BFS
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": None,
-                "kernel": "advance::LoadBalancedKernel", "launches": launches,
-                "avg_launch_ms": round(kernel_ms / max(launches, 1), 5),
-                "alg_bytes_per_launch": round(balg / max(launches, 1), 1)}
+                "kernel": names.get(dom, str(dom)),
+                "kernel_share_of_device_time": round(by_kind[dom][1] / kernel_ms, 4) if kernel_ms else None,
+                "kernel_launches": by_kind[dom][0] if by_kind else 0,
+                "kernel_avg_launch_ms": round(by_kind[dom][1] / max(by_kind[dom][0], 1), 5) if by_kind else None,
+                "all_launches": launches, "all_kernel_ms_per_bfs": round(kernel_ms / max(min(args.steps, len(sources)), 1), 5),
+                "alg_bytes_per_bfs": round(balg / max(min(args.steps, len(sources)), 1), 1),
+                "by_kernel_ms": {names.get(kd, str(kd)): round(v[1], 4) for kd, v in sorted(by_kind.items())}}
     iprob.close()
 
     cpu = None
@@ -153,7 +182,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
             cpu_edges += o.bfs_stats(g, ref_labels)[1]
             if k == 0:
                 prob.reset(s)
-                prob.enact(s)
+                prob.enact(s, traversal_mode=mode)
                 got, _ = prob.extract()
                 parity = bool((got == ref_labels).all())
         cpu = {"value": round(cpu_edges / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
@@ -167,11 +196,12 @@ def bench_single(args, torch, ga, devgraph, device_index):
         "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "BFS idempotent, R-MAT scale-%d (a=.55 b=.2 c=.2 d=.05, %d pairs/vertex mirrored, "
+        "config": {"workload": "BFS idempotent %s, R-MAT scale-%d (a=.55 b=.2 c=.2 d=.05, %d pairs/vertex mirrored, "
                                "seed 0x%x): n=%d, m=%d directed edges; sources: largest-degree + 64 seeded"
-                               % (args.scale, args.edge_factor, args.seed, n, m),
+                               % ("direction-optimizing (traversal_mode 2)" if mode == 2 else "top-down (traversal_mode 0)",
+                                  args.scale, args.edge_factor, args.seed, n, m),
                    "search_depth_src0": depth, "graph_build_s": round(build_s, 2), "max_degree": maxdeg},
-        "enact_mteps": round(enact_mteps, 2), "enact_ms_per_step": round(enact_ms / args.steps, 4),
+        "enact_mteps": round(enact_mteps, 2), "topdown_only_enact_mteps": None if topdown_mteps is None else round(topdown_mteps, 2), "enact_ms_per_step": round(enact_ms / args.steps, 4),
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_oracle": parity,
         "roofline": roofline, "cpu_baseline": cpu,
