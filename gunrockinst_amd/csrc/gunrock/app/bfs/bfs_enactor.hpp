@@ -95,6 +95,7 @@ class BFSEnactor : public EnactorBase {
         const int conv_grid = cu_count * 4;
         const size_t mask_bytes = sizeof(unsigned) * static_cast<size_t>(problem->MaskWords() + 2);
         long long unexplored_edges = problem->edges;
+        // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])
         bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
         int cur_mask = 0;
         int selector = 0;
@@ -109,14 +110,17 @@ class BFSEnactor : public EnactorBase {
             //      dobfs_enactor.cuh:397,569) ----
             if (dobfs && !bottom_up &&
                 static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges)) {
-                // queue -> bitmap
-                if ((retval = util::GRError(hipMemsetAsync(ds->d_frontier_mask[cur_mask], 0, mask_bytes, stream),
-                                            "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
-                    break;
-                hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
-                                   stream, gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length),
-                                   ds->d_frontier_mask[cur_mask]);
-                if ((retval = util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__))) break;
+                // queue -> bitmap: the frontier is exactly what the last top-down level added to the visited bitmap
+                // (zero-degree discoveries included: they have no out-edges, so nobody can adopt them as parent)
+                {
+                    const long long words64 = static_cast<long long>(problem->MaskWords()) / 2;
+                    hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(conv_grid), dim3(256), 0, stream,
+                                       reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
+                                       reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
+                                       reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), words64);
+                    if ((retval = util::GRError("BitmapDiffKernel launch failed", __FILE__, __LINE__))) break;
+                    cur_mask = 0;
+                }
                 bottom_up = true;
             } else if (dobfs && bottom_up &&
                        static_cast<double>(queue_length) * problem->beta < static_cast<double>(problem->nodes)) {
@@ -136,19 +140,27 @@ class BFSEnactor : public EnactorBase {
             }
             unexplored_edges -= in_edges;
             ds->iteration = static_cast<VertexId>(iteration);
+            if (dobfs && !bottom_up) {
+                // snapshot of the visited bitmap before this top-down level (n/8 bytes, device to device)
+                if ((retval = util::GRError(hipMemcpyAsync(ds->d_frontier_mask[1], ds->d_visited_mask, mask_bytes,
+                                                           hipMemcpyDeviceToDevice, stream),
+                                            "BFSEnactor visited snapshot failed", __FILE__, __LINE__)))
+                    break;
+            }
 
             if (bottom_up) {
                 oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
                 bargs.nodes = problem->nodes;
                 bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
                 bargs.d_inv_column_indices = ds->d_inv_column_indices;
+                bargs.d_inv_heads = ds->d_inv_heads;
                 oprtr::advance::BitmapLookup<VertexId> lookup{ds->d_frontier_mask[cur_mask]};
                 bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[cur_mask ^ 1]);
                 bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
                 bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
-                const long long words = (static_cast<long long>(problem->nodes) + 63) / 64;
-                long long grid = (words + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+                const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + 15) / 16;  // 16 words per wave step
+                long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
                 const long long cap = max_grid_size > 0 ? max_grid_size : cu_count * 8;
                 if (grid > cap) grid = cap;
                 if (grid < 1) grid = 1;

@@ -20,11 +20,72 @@
 #include <hip/hip_runtime.h>
 
 #include <gunrock/app/problem_base.hpp>
+#include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
 namespace gunrock {
 namespace app {
 namespace bfs {
+
+// bit v = (v has no in-edge); one wave per 64 vertices, the word is written whole
+template <typename SizeT>
+__global__ void NoInEdgeMaskKernel(const SizeT *d_inv_row_offsets, long long nodes, long long words64, unsigned long long *d_mask)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / 64;
+    const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / 64;
+    for (long long w = wave0; w < words64; w += nwaves) {
+        const long long v = w * 64 + lane;
+        const bool none = v < nodes && d_inv_row_offsets[v + 1] == d_inv_row_offsets[v];
+        const unsigned long long m = __ballot(none);
+        if (lane == 0) d_mask[w] = m;
+    }
+}
+
+// Reset in one launch: 16-byte stores for labels / preds, the source patched in flight, queue entry 0 seeded.
+template <typename VertexId, typename SizeT, bool PRED>
+__global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *d_visited, const unsigned *d_never,
+                               unsigned *d_snapshot, long long nodes,
+                               long long mask_words, VertexId src, const SizeT *d_row_offsets,
+                               util::Frontier<VertexId, SizeT> queue0, SizeT *d_src_row)
+{
+    typedef __attribute__((ext_vector_type(4))) int V4;
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long nvec = nodes / 4;
+    V4 *labels4 = reinterpret_cast<V4 *>(d_labels);
+    V4 *preds4 = reinterpret_cast<V4 *>(d_preds);
+    for (long long k = tid; k < nvec; k += stride) {
+        V4 l = {-1, -1, -1, -1};
+        V4 p = {-2, -2, -2, -2};
+        if (src >= 0 && k == src / 4) {
+            l[src & 3] = 0;
+            p[src & 3] = -1;
+        }
+        labels4[k] = l;
+        if (PRED) preds4[k] = p;
+    }
+    for (long long i = nvec * 4 + tid; i < nodes; i += stride) {
+        d_labels[i] = (i == src) ? 0 : -1;
+        if (PRED) d_preds[i] = (i == src) ? -1 : -2;
+    }
+    for (long long w = tid; w < mask_words; w += stride)
+    {
+        const unsigned never = d_never ? d_never[w] : 0u;
+        const unsigned src_bit = (src >= 0 && w == (src >> 5)) ? (1u << (src & 31)) : 0u;
+        d_visited[w] = never | src_bit;
+        // "visited before the search": what a direction switch at level 0 diffs against; the source must survive the diff
+        if (d_snapshot) d_snapshot[w] = never & ~src_bit;
+    }
+    if (tid == 0 && src >= 0) {
+        const SizeT begin = d_row_offsets[src], end = d_row_offsets[src + 1];
+        queue0.v[0] = src;
+        queue0.row_start[0] = begin;
+        queue0.scan[0] = 0;
+        d_src_row[0] = begin;
+        d_src_row[1] = end;
+    }
+}
 
 template <typename _VertexId, typename _SizeT, typename _Value, bool _MARK_PREDECESSORS,
           bool _ENABLE_IDEMPOTENCE, bool _USE_DOUBLE_BUFFER>
@@ -43,6 +104,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         VertexId iteration = 0;               // current BSP level (labels written = iteration + 1)
         // direction-optimizing traversal (reference app/dobfs: d_frontier_map_in/out, dobfs_problem.cuh):
         unsigned *d_frontier_mask[2] = {nullptr, nullptr};  // 1 bit per vertex: current / next frontier
+        unsigned *d_never_mask = nullptr;                   // vertices without in-edges: nothing can ever discover them
+        int2 *d_inv_heads = nullptr;                        // first two in-neighbours per vertex (bottom_up.hpp)
         const SizeT *d_inv_row_offsets = nullptr;           // in-neighbour CSR (CSC of the graph)
         const VertexId *d_inv_column_indices = nullptr;
     };
@@ -67,10 +130,14 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                 if (ds->d_visited_mask) util::GRError(hipFree(ds->d_visited_mask), "BFSProblem hipFree d_visited_mask failed", __FILE__, __LINE__);
                 for (int i = 0; i < 2; ++i)
                     if (ds->d_frontier_mask[i]) util::GRError(hipFree(ds->d_frontier_mask[i]), "BFSProblem hipFree d_frontier_mask failed", __FILE__, __LINE__);
+                if (ds->d_never_mask) util::GRError(hipFree(ds->d_never_mask), "BFSProblem hipFree d_never_mask failed", __FILE__, __LINE__);
+                if (ds->d_inv_heads) util::GRError(hipFree(ds->d_inv_heads), "BFSProblem hipFree d_inv_heads failed", __FILE__, __LINE__);
                 delete ds;
             }
             delete[] data_slices;
         }
+        if (h_src_row) util::GRError(hipHostFree(h_src_row), "BFSProblem hipHostFree failed", __FILE__, __LINE__);
+        if (d_src_row) util::GRError(hipFree(d_src_row), "BFSProblem hipFree failed", __FILE__, __LINE__);
     }
 
     // bitmaps are sized in whole 64-bit words: one wave owns one word in the bottom-up sweep
@@ -89,6 +156,32 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             if (!ds->d_frontier_mask[i])
                 GR_CHECK(hipMalloc(&ds->d_frontier_mask[i], sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
                          "BFSProblem hipMalloc d_frontier_mask failed");
+        // Static per graph: bit v set when v has no in-edge.  Reset preloads the visited bitmap with it, so the bottom-up
+        // sweep skips those vertices (half of an R-MAT graph) without touching their row offsets, 64 at a time.
+        if (!ds->d_never_mask)
+            GR_CHECK(hipMalloc(&ds->d_never_mask, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
+                     "BFSProblem hipMalloc d_never_mask failed");
+        if (!ds->d_inv_heads)
+            GR_CHECK(hipMalloc(&ds->d_inv_heads, sizeof(int2) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)),
+                     "BFSProblem hipMalloc d_inv_heads failed");
+        if (this->nodes > 0) {
+            long long grid = (static_cast<long long>(this->nodes) + 255) / 256;
+            if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<VertexId, SizeT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               this->graph_slices[0]->stream, d_inv_row_offsets, d_inv_column_indices,
+                               static_cast<long long>(this->nodes), ds->d_inv_heads);
+            GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
+        }
+        {
+            const long long words64 = static_cast<long long>(MaskWords()) / 2 + 1;
+            long long grid = (words64 + 3) / 4;
+            if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL((NoInEdgeMaskKernel<SizeT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               this->graph_slices[0]->stream, d_inv_row_offsets, static_cast<long long>(this->nodes), words64,
+                               reinterpret_cast<unsigned long long *>(ds->d_never_mask));
+            GR_CHECK(hipGetLastError(), "NoInEdgeMaskKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(this->graph_slices[0]->stream), "NoInEdgeMaskKernel failed");
+        }
         if (alpha_ > 0) alpha = alpha_;
         if (beta_ > 0) beta = beta_;
         direction_optimizing = true;
@@ -128,7 +221,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         return AllocData();
     }
 
-    // Source degree / row start are read back from HBM (8 bytes) so Reset works for device-resident graphs.
+    // One fused kernel (labels = -1, preds = -2, visited = 0, source seeded, queue seeded) and one 8-byte read-back of
+    // the source's row extent -- the reference issues 3 <<<128,128>>> memsets and 3-4 tiny H2D copies (:298-357).
     hipError_t Reset(VertexId src, FrontierType frontier_type, double queue_sizing)
     {
         hipError_t retval = hipSuccess;
@@ -136,33 +230,29 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         GraphSlice<VertexId, SizeT, Value> *gs = this->graph_slices[0];
         DataSlice *ds = data_slices[0];
         hipStream_t stream = gs->stream;
-        util::Memset(ds->d_labels, static_cast<VertexId>(-1), this->nodes, stream);
-        if (MARK_PREDECESSORS) util::Memset(ds->d_preds, static_cast<VertexId>(-2), this->nodes, stream);
-        util::Memset(ds->d_visited_mask, 0u, MaskWords() + 2, stream);
-        ds->iteration = 0;
-        src_row[0] = src_row[1] = 0;
-        if (src >= 0 && src < this->nodes) {
-            GR_CHECK(hipMemcpyAsync(src_row, gs->d_row_offsets + src, 2 * sizeof(SizeT), hipMemcpyDeviceToHost, stream),
-                     "BFSProblem read source row failed");
-            const VertexId zero = 0, minus_one = -1;
-            const unsigned bit = 1u << (src & 31);
-            GR_CHECK(hipMemcpyAsync(ds->d_labels + src, &zero, sizeof(VertexId), hipMemcpyHostToDevice, stream),
-                     "BFSProblem seed label failed");
-            if (MARK_PREDECESSORS)
-                GR_CHECK(hipMemcpyAsync(ds->d_preds + src, &minus_one, sizeof(VertexId), hipMemcpyHostToDevice, stream),
-                         "BFSProblem seed pred failed");
-            GR_CHECK(hipMemcpyAsync(ds->d_visited_mask + (src >> 5), &bit, sizeof(unsigned), hipMemcpyHostToDevice, stream),
-                     "BFSProblem seed mask failed");
-            const SizeT zero_prefix = 0;
-            GR_CHECK(hipMemcpyAsync(gs->frontier_queues[0].v, &src, sizeof(VertexId), hipMemcpyHostToDevice, stream),
-                     "BFSProblem seed queue failed");
-            GR_CHECK(hipMemcpyAsync(gs->frontier_queues[0].scan, &zero_prefix, sizeof(SizeT), hipMemcpyHostToDevice, stream),
-                     "BFSProblem seed queue failed");
-            GR_CHECK(hipStreamSynchronize(stream), "BFSProblem Reset sync failed");
-            GR_CHECK(hipMemcpyAsync(gs->frontier_queues[0].row_start, &src_row[0], sizeof(SizeT), hipMemcpyHostToDevice, stream),
-                     "BFSProblem seed queue failed");
+        if (!h_src_row) {
+            GR_CHECK(hipHostMalloc(&h_src_row, sizeof(SizeT) * 2, hipHostMallocDefault), "BFSProblem hipHostMalloc failed");
+            GR_CHECK(hipMalloc(&d_src_row, sizeof(SizeT) * 2), "BFSProblem hipMalloc d_src_row failed");
         }
+        ds->iteration = 0;
+        h_src_row[0] = h_src_row[1] = 0;
+        const bool valid = src >= 0 && src < this->nodes;
+        const long long work = (static_cast<long long>(this->nodes) + 3) / 4;
+        long long grid = (work + 255) / 256;
+        if (grid > 2048) grid = 2048;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((BfsResetKernel<VertexId, SizeT, MARK_PREDECESSORS>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream,
+                           ds->d_labels, ds->d_preds, ds->d_visited_mask, direction_optimizing ? ds->d_never_mask : nullptr,
+                           direction_optimizing ? ds->d_frontier_mask[1] : nullptr, static_cast<long long>(this->nodes),
+                           static_cast<long long>(MaskWords() + 2), valid ? src : static_cast<VertexId>(-1), gs->d_row_offsets,
+                           gs->frontier_queues[0], d_src_row);
+        GR_CHECK(hipGetLastError(), "BfsResetKernel launch failed");
+        if (valid)
+            GR_CHECK(hipMemcpyAsync(h_src_row, d_src_row, sizeof(SizeT) * 2, hipMemcpyDeviceToHost, stream),
+                     "BFSProblem read source row failed");
         GR_CHECK(hipStreamSynchronize(stream), "BFSProblem Reset sync failed");
+        src_row[0] = h_src_row[0];
+        src_row[1] = h_src_row[1];
         source = src;
         return retval;
     }
@@ -187,6 +277,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
 
     VertexId source = -1;
     SizeT src_row[2] = {0, 0};
+    SizeT *h_src_row = nullptr;  // pinned
+    SizeT *d_src_row = nullptr;
 };
 
 }  // namespace bfs

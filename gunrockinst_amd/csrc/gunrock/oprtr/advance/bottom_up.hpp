@@ -40,6 +40,17 @@ __global__ void QueueToBitmapKernel(const VertexId *d_queue, SizeT length, unsig
     }
 }
 
+// ---- frontier bitmap = visited now XOR visited before the last top-down level (no atomics, 3 x n/8 bytes) ----
+// 218 K scattered atomicOr for the level-1 frontier of a scale-24 search cost 144 us (each is a 64-byte memory-side
+// request); two streaming bitmap reads cost ~3 us.
+__global__ inline void BitmapDiffKernel(const unsigned long long *d_now, const unsigned long long *d_before,
+                                        unsigned long long *d_out, long long words)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; w < words; w += stride)
+        d_out[w] = d_now[w] ^ d_before[w];
+}
+
 // Frontier membership tests for the bottom-up sweep.
 // BitmapLookup: one bitmap indexed by vertex id (single GPU).
 // StripedBitmapLookup: vertex-cut over P ranks, owner = v mod P, local id = v div P (the reference's only multi-GPU
@@ -69,11 +80,32 @@ struct BottomUpArgs {
     SizeT nodes;
     const SizeT *d_inv_row_offsets;
     const VertexId *d_inv_column_indices;
+    const int2 *d_inv_heads;                // first two in-neighbours per vertex (-1 padded)
     unsigned long long *d_frontier_out;     // next frontier bitmap, every word is written
     unsigned long long *d_visited;          // visited bitmap, owner-updated
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
 };
+
+struct __attribute__((packed, aligned(4))) Quad {
+    int v[4];
+};
+
+// first two in-neighbours of every vertex, -1 padded: the "adjacency head" (8 bytes per vertex, built once per
+// inverse graph).  Consecutive vertices have consecutive heads, so a wave's 64 lanes read 512 contiguous bytes,
+// where going to the CSR row costs a 64-byte line per vertex to use 4-8 bytes of it.
+template <typename VertexId, typename SizeT>
+__global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_column_indices, long long nodes, int2 *d_heads)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v < nodes; v += stride) {
+        const SizeT b = d_row_offsets[v], e = d_row_offsets[v + 1];
+        int2 h;
+        h.x = (e - b > 0) ? d_column_indices[b] : -1;
+        h.y = (e - b > 1) ? d_column_indices[b + 1] : -1;
+        d_heads[v] = h;
+    }
+}
 
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
 __global__ __launch_bounds__(THREADS) void BottomUpKernel(
@@ -83,6 +115,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
     constexpr int WAVES = THREADS / util::kWaveSize;
+    constexpr int STEP_WORDS = 16;  // bitmap words (x64 vertices) a wave takes per step; lanes 0..15 own one word each
     __shared__ unsigned long long s_total[WAVES];
 
     const int tid = threadIdx.x;
@@ -90,68 +123,97 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     if (blockIdx.x == 0 && tid == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
 
     const long long words = (static_cast<long long>(a.nodes) + 63) / 64;
+    const long long steps = (words + STEP_WORDS - 1) / STEP_WORDS;
     const long long wave0 = (static_cast<long long>(blockIdx.x) * THREADS + tid) / util::kWaveSize;
     const long long nwaves = static_cast<long long>(gridDim.x) * WAVES;
     const VertexId new_label = slice.iteration + 1;
 
     unsigned found_count = 0;
     unsigned found_edges = 0;
-    for (long long w = wave0; w < words; w += nwaves) {
-        const unsigned long long vis = a.d_visited[w];  // wave-uniform address
-        const VertexId v = static_cast<VertexId>(w * 64 + lane);
-        bool open = v < a.nodes && ((vis >> lane) & 1ull) == 0;
-        unsigned long long found_mask = 0;
-        if (__ballot(open) != 0) {  // wave-uniform: some vertex of this word is still unvisited
-            SizeT pos = 0, end = 0;
-            if (open) {
-                pos = a.d_inv_row_offsets[v];
-                end = a.d_inv_row_offsets[v + 1];
-            }
-            const SizeT degree = end - pos;
-            open = open && degree > 0;
+    for (long long step = wave0; step < steps; step += nwaves) {
+        // lanes 0..STEP_WORDS-1 read the visited words of this step with one coalesced load
+        const long long my_word = step * STEP_WORDS + lane;
+        const bool owns_word = lane < STEP_WORDS && my_word < words;
+        unsigned long long my_vis = ~0ull;
+        if (owns_word) my_vis = a.d_visited[my_word];
+        unsigned long long my_open = ~my_vis;
+        if (owns_word && (my_word + 1) * 64 > a.nodes) {  // last word: bits past the vertex count are not vertices
+            const int valid = static_cast<int>(a.nodes - my_word * 64);
+            my_open &= (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
+        }
+        unsigned long long my_found = 0;
+        unsigned long long todo_words = __ballot(owns_word && my_open != 0);
+        while (todo_words) {  // wave-uniform loop over the words that still have unvisited vertices
+            const int j = __ffsll(static_cast<long long>(todo_words)) - 1;
+            todo_words &= todo_words - 1;
+            const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
+            const VertexId v = static_cast<VertexId>((step * STEP_WORDS + j) * 64 + lane);
+            bool open = (open_mask >> lane) & 1ull;
             VertexId parent = -1;
+            SizeT pos = 0, end = 0;
 
-            // phase A/B: the lane probes PROBE edges at a time, all loads in flight, for up to SOLO_LIMIT edges
-            for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
-                if (__ballot(open && parent < 0 && pos < end) == 0) break;  // wave-uniform
-                VertexId nb[PROBE];
-                bool fw[PROBE];
-#pragma unroll
-                for (int j = 0; j < PROBE; ++j)
-                    nb[j] = (open && parent < 0 && pos + j < end) ? a.d_inv_column_indices[pos + j] : static_cast<VertexId>(-1);
-#pragma unroll
-                for (int j = 0; j < PROBE; ++j)
-                    fw[j] = (nb[j] >= 0) ? in_frontier(nb[j]) : false;
-#pragma unroll
-                for (int j = 0; j < PROBE; ++j)
-                    if (parent < 0 && fw[j]) parent = nb[j];
-                pos += PROBE;
+            // phase H: the adjacency head (coalesced 8 bytes per lane); R-MAT needs 1.2 probes per vertex on average
+            // at the heavy level, so most vertices never touch their CSR row
+            int2 head = {-1, -1};
+            if (open) head = a.d_inv_heads[v];
+            open = open && head.x >= 0;
+            if (open && in_frontier(head.x)) parent = head.x;
+            if (__ballot(open && parent < 0 && head.y >= 0) != 0) {
+                if (open && parent < 0 && head.y >= 0 && in_frontier(head.y)) parent = head.y;
             }
-
-            // phase C: rows still unresolved are swept by the whole wave, 64 in-edges per step
-            unsigned long long todo = __ballot(open && parent < 0 && pos < end);
-            while (todo) {
-                const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-                SizeT p = __shfl(pos, leader, util::kWaveSize);
-                const SizeT e = __shfl(end, leader, util::kWaveSize);
-                VertexId hit_parent = -1;
-                for (; p < e; p += util::kWaveSize) {
-                    const SizeT mine = p + static_cast<SizeT>(lane);
-                    VertexId u = -1;
-                    if (mine < e) u = a.d_inv_column_indices[mine];
-                    bool hit = false;
-                    if (u >= 0) hit = in_frontier(u);
-                    const unsigned long long hm = __ballot(hit);
-                    if (hm) {
-                        hit_parent = __shfl(u, __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
-                        break;
+            // rows longer than the head continue in the CSR row from its third entry
+            bool more = open && parent < 0 && head.y >= 0;
+            if (__ballot(more) != 0) {
+                if (more) {
+                    pos = a.d_inv_row_offsets[v] + 2;
+                    end = a.d_inv_row_offsets[v + 1];
+                }
+                // phase B: PROBE edges at a time, loads in flight together, up to SOLO_LIMIT edges per lane
+                for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
+                    if (__ballot(more && parent < 0 && pos < end) == 0) break;  // wave-uniform
+                    VertexId nb[PROBE];
+                    bool fw[PROBE];
+                    if (more && parent < 0 && pos + PROBE <= end && PROBE == 4) {
+                        const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + pos);  // one 16-byte load
+#pragma unroll
+                        for (int k = 0; k < PROBE; ++k) nb[k] = q.v[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PROBE; ++k)
+                            nb[k] = (more && parent < 0 && pos + k < end) ? a.d_inv_column_indices[pos + k] : static_cast<VertexId>(-1);
                     }
+#pragma unroll
+                    for (int k = 0; k < PROBE; ++k) fw[k] = (nb[k] >= 0) ? in_frontier(nb[k]) : false;
+#pragma unroll
+                    for (int k = 0; k < PROBE; ++k)
+                        if (parent < 0 && fw[k]) parent = nb[k];
+                    pos += PROBE;
                 }
-                if (static_cast<int>(lane) == leader) {
-                    parent = hit_parent;
-                    pos = end;
+                // phase C: rows still unresolved are swept by the whole wave, 64 in-edges per step
+                unsigned long long todo = __ballot(more && parent < 0 && pos < end);
+                while (todo) {
+                    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+                    SizeT p = __shfl(pos, leader, util::kWaveSize);
+                    const SizeT e = __shfl(end, leader, util::kWaveSize);
+                    VertexId hit_parent = -1;
+                    for (; p < e; p += util::kWaveSize) {
+                        const SizeT mine = p + static_cast<SizeT>(lane);
+                        VertexId u = -1;
+                        if (mine < e) u = a.d_inv_column_indices[mine];
+                        bool hit = false;
+                        if (u >= 0) hit = in_frontier(u);
+                        const unsigned long long hm = __ballot(hit);
+                        if (hm) {
+                            hit_parent = __shfl(u, __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
+                            break;
+                        }
+                    }
+                    if (static_cast<int>(lane) == leader) {
+                        parent = hit_parent;
+                        pos = end;
+                    }
+                    todo &= todo - 1;
                 }
-                todo &= todo - 1;
             }
 
             const bool found = open && parent >= 0;
@@ -159,13 +221,14 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 slice.d_labels[v] = new_label;
                 if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
                 found_count += 1;
-                found_edges += static_cast<unsigned>(degree);
+                found_edges += static_cast<unsigned>(a.d_inv_row_offsets[v + 1] - a.d_inv_row_offsets[v]);
             }
-            found_mask = __ballot(found);
+            const unsigned long long fm = __ballot(found);
+            if (static_cast<int>(lane) == j) my_found = fm;
         }
-        if (lane == 0) {
-            a.d_frontier_out[w] = found_mask;
-            if (found_mask) a.d_visited[w] = vis | found_mask;
+        if (owns_word) {  // coalesced write-back of the step's words
+            a.d_frontier_out[my_word] = my_found;
+            if (my_found) a.d_visited[my_word] = my_vis | my_found;
         }
     }
 

@@ -117,6 +117,7 @@ struct Pbfs : app::EnactorBase {
     int *d_row_offsets = nullptr, *d_col_indices = nullptr;  // borrowed
     PbfsProblem::DataSlice ds{};
     unsigned *d_frontier_mask[2] = {nullptr, nullptr};
+    int2 *d_heads = nullptr;
     util::Frontier<int, int> queues[2];
     int *d_candidates = nullptr, *d_send = nullptr;
     unsigned *d_counts = nullptr, *h_counts = nullptr;  // 2 * 64: counts, cursors
@@ -151,6 +152,12 @@ struct Pbfs : app::EnactorBase {
             GR_CHECK(hipMalloc(&queues[i].scan, sizeof(int) * cap), "Pbfs hipMalloc failed");
             queues[i].capacity = static_cast<int>(cap);
         }
+        GR_CHECK(hipMalloc(&d_heads, sizeof(int2) * nl), "Pbfs hipMalloc failed");
+        if (n_local > 0) {
+            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<int, int>), dim3((n_local + 255) / 256 < 4096 ? (n_local + 255) / 256 : 4096),
+                               dim3(256), 0, stream, d_row_offsets, d_col_indices, static_cast<long long>(n_local), d_heads);
+            GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
+        }
         // a rank forwards each global vertex at most once over the whole search
         candidate_capacity = n_global + 1024;
         GR_CHECK(hipMalloc(&d_candidates, sizeof(int) * static_cast<size_t>(candidate_capacity)), "Pbfs hipMalloc failed");
@@ -171,6 +178,7 @@ struct Pbfs : app::EnactorBase {
             if (queues[i].row_start) hipFree(queues[i].row_start);
             if (queues[i].scan) hipFree(queues[i].scan);
         }
+        if (d_heads) hipFree(d_heads);
         if (d_candidates) hipFree(d_candidates);
         if (d_send) hipFree(d_send);
         if (d_counts) hipFree(d_counts);
@@ -311,14 +319,15 @@ struct Pbfs : app::EnactorBase {
         b.nodes = n_local;
         b.d_inv_row_offsets = d_row_offsets;
         b.d_inv_column_indices = d_col_indices;
+        b.d_inv_heads = d_heads;
         b.d_frontier_out = reinterpret_cast<unsigned long long *>(d_frontier_mask[cur_mask ^ 1]);
         b.d_visited = reinterpret_cast<unsigned long long *>(ds.d_visited_mask);
         b.d_tail_out = work_progress.d_tail + 1;
         b.d_tail_clear = nullptr;
         ds.iteration = level;
         oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
-        const long long words = (static_cast<long long>(n_local) + 63) / 64;
-        long long grid = (words + 3) / 4;
+        const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + 15) / 16;
+        long long grid = (bu_steps + 3) / 4;
         if (grid > cu_count * 8) grid = cu_count * 8;
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 4, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),

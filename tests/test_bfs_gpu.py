@@ -194,3 +194,26 @@ def test_dobfs_edge_cases():
     _check(g, 0, labels, preds, st)
     labels, preds, st, _ = _run(g, n // 2, True, True, mode=2, alpha=1e9, beta=1e9)
     _check(g, n // 2, labels, preds, st)
+
+
+def test_dobfs_directed_graph_with_explicit_inverse():
+    # directed R-MAT: the in-neighbour CSR is a different graph; sources without in-edges and vertices without
+    # in-edges (never discoverable, pre-marked in the visited bitmap) must behave
+    g = o.rmat_seeded(14, 8 << 14, undirected=False)
+    src_of = np.repeat(np.arange(g.nodes, dtype=np.int32), np.diff(g.row_offsets))
+    inv0 = ga.HostGraph.from_coo(g.nodes, g.col_indices, src_of)
+    import torch
+    iro = torch.tensor(inv0.row_offsets, dtype=torch.int32, device="cuda")
+    ici = torch.tensor(inv0.col_indices, dtype=torch.int32, device="cuda")
+    outdeg, indeg = np.diff(g.row_offsets), np.diff(inv0.row_offsets)
+    picks = [int(np.argmax(outdeg)), int(np.nonzero((indeg == 0) & (outdeg > 0))[0][0]), int(np.nonzero(outdeg == 0)[0][0])]
+    for src in picks:
+        for alpha, beta in [(0.0, 0.0), (1e9, 1.0), (1e9, 1e9)]:
+            p = ga.BfsProblem(True, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph(iro.data_ptr(), ici.data_ptr(), alpha, beta)
+            p.reset(src)
+            p.enact(src, traversal_mode=2)
+            labels, preds = p.extract()
+            st = p.stats()
+            p.close()
+            _check(g, src, labels, preds, st)
