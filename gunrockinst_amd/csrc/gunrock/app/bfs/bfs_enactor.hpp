@@ -159,9 +159,10 @@ class BFSEnactor : public EnactorBase {
                 bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
                 bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
-                const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + 15) / 16;  // 16 words per wave step
+                const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
                 long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
-                const long long cap = max_grid_size > 0 ? max_grid_size : cu_count * 8;
+                const long long cap = max_grid_size > 0 ? max_grid_size
+                    : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
                 if (grid > cap) grid = cap;
                 if (grid < 1) grid = 1;
                 hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
@@ -180,7 +181,7 @@ class BFSEnactor : public EnactorBase {
                 args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
                 args.d_overflow = work_progress.d_overflow;
                 if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
-                         args, *ds, enactor_stats.advance_grid_size, stream, oprtr::advance::V2V)))
+                         args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;
                 selector ^= 1;
             }

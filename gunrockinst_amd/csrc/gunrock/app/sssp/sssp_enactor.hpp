@@ -118,7 +118,7 @@ class SSSPEnactor : public EnactorBase {
                 args.d_overflow = work_progress.d_overflow;
                 if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
                 if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, SSSPProblem, SsspFunctor, false>(
-                         args, *ds, grid, stream, oprtr::advance::V2V)))
+                         args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;
                 if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                 if ((retval = read_tails())) break;

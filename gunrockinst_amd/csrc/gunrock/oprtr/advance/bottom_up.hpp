@@ -87,6 +87,9 @@ struct BottomUpArgs {
     unsigned long long *d_tail_clear;
 };
 
+// 64-vertex bitmap words one wave takes per step of the bottom-up sweep (launch code sizes the grid from it)
+constexpr int kBottomUpStepWords = 16;
+
 struct __attribute__((packed, aligned(4))) Quad {
     int v[4];
 };
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
     constexpr int WAVES = THREADS / util::kWaveSize;
-    constexpr int STEP_WORDS = 16;  // bitmap words (x64 vertices) a wave takes per step; lanes 0..15 own one word each
+    constexpr int STEP_WORDS = kBottomUpStepWords;  // bitmap words (x64 vertices) a wave takes per step; lanes 0..STEP_WORDS-1 own one word each
     __shared__ unsigned long long s_total[WAVES];
 
     const int tid = threadIdx.x;

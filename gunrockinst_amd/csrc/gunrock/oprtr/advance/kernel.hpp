@@ -243,6 +243,8 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
 {
     if (args.in_len <= 0 || args.in_edges <= 0) return hipSuccess;
     const long long tiles = (static_cast<long long>(args.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    if (max_grid_size <= 0)  // one resident wave of workgroups, each with a contiguous share of the tiles
+        max_grid_size = util::ResidentGrid(LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>, KernelPolicy::THREADS);
     long long grid = tiles < max_grid_size ? tiles : max_grid_size;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>), dim3(static_cast<unsigned>(grid)),

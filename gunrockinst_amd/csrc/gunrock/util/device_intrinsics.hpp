@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+
 namespace gunrock {
 namespace util {
 
@@ -84,6 +86,26 @@ __device__ __forceinline__ unsigned LoadAgent(const unsigned *p)
 __device__ __forceinline__ int LoadAgent(const int *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Workgroups of `kernel` that fit on the device at once (occupancy API x CU count), cached per kernel instantiation.
+// Grid-stride kernels launched with exactly this many workgroups run as ONE wave of blocks: a grid of
+// CUs x "hoped-for blocks per CU" that exceeds residency leaves a second, mostly empty round (a 1.3x tail at 6 of 8).
+template <typename Kernel>
+inline int ResidentGrid(Kernel kernel, int threads)
+{
+    static std::map<const void *, int> cache;  // keyed by the kernel's address (the template is keyed by its TYPE only)
+    int &cached = cache[reinterpret_cast<const void *>(kernel)];
+    if (cached == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        int cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        cached = per_cu * cus;
+    }
+    return cached;
 }
 
 }  // namespace util

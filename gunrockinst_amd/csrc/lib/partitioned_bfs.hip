@@ -242,8 +242,7 @@ struct Pbfs : app::EnactorBase {
             args.d_overflow = work_progress.d_overflow;
             ds.iteration = level;
             typedef oprtr::advance::KernelPolicy<256, 8, 3, oprtr::advance::LB> Policy;
-            if ((retval = oprtr::advance::LaunchKernel<Policy, PbfsProblem, SendFunctor, false>(
-                     args, ds, enactor_stats.advance_grid_size, stream)))
+            if ((retval = oprtr::advance::LaunchKernel<Policy, PbfsProblem, SendFunctor, false>(args, ds, 0, stream)))
                 return retval;
             if ((retval = work_progress.GetTail(0, candidates, unused, stream))) return retval;
         }
@@ -326,9 +325,10 @@ struct Pbfs : app::EnactorBase {
         b.d_tail_clear = nullptr;
         ds.iteration = level;
         oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
-        const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + 15) / 16;
+        const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
         long long grid = (bu_steps + 3) / 4;
-        if (grid > cu_count * 8) grid = cu_count * 8;
+        const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 4, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
+        if (grid > cap) grid = cap;
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 4, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
                            dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
