@@ -13,9 +13,9 @@
 //     and hubs have small ids, so parents sit at the front), keeps going alone for a bounded number of
 //     edges, and hands long unlucky rows to the whole wave (64 edges per step, ballot early-exit) so a
 //     single long row cannot stall 63 idle lanes;
-//   * found vertices and their degrees are reduced per workgroup and added to the step's packed tail
-//     (vertices | edges<<32), the same word the forward advance produces, so the enactor's heuristic and
-//     statistics see one format.
+//   * found vertices are counted per workgroup and added to the step's packed tail (same word the forward advance
+//     produces; the edge half stays 0 -- degrees are not needed while the search runs bottom-up, and the
+//     bitmap -> queue conversion recomputes them exactly when it returns to top-down).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -88,7 +88,7 @@ struct BottomUpArgs {
 };
 
 // 64-vertex bitmap words one wave takes per step of the bottom-up sweep (launch code sizes the grid from it)
-constexpr int kBottomUpStepWords = 16;
+constexpr int kBottomUpStepWords = 8;
 
 struct __attribute__((packed, aligned(4))) Quad {
     int v[4];
@@ -145,55 +145,90 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
             my_open &= (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
         }
         unsigned long long my_found = 0;
-        unsigned long long todo_words = __ballot(owns_word && my_open != 0);
-        while (todo_words) {  // wave-uniform loop over the words that still have unvisited vertices
-            const int j = __ffsll(static_cast<long long>(todo_words)) - 1;
-            todo_words &= todo_words - 1;
-            const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
-            const VertexId v = static_cast<VertexId>((step * STEP_WORDS + j) * 64 + lane);
-            bool open = (open_mask >> lane) & 1ull;
-            VertexId parent = -1;
-            SizeT pos = 0, end = 0;
-
-            // phase H: the adjacency head (coalesced 8 bytes per lane); R-MAT needs 1.2 probes per vertex on average
-            // at the heavy level, so most vertices never touch their CSR row
-            int2 head = {-1, -1};
-            if (open) head = a.d_inv_heads[v];
-            open = open && head.x >= 0;
-            if (open && in_frontier(head.x)) parent = head.x;
-            if (__ballot(open && parent < 0 && head.y >= 0) != 0) {
-                if (open && parent < 0 && head.y >= 0 && in_frontier(head.y)) parent = head.y;
+        if (__ballot(owns_word && my_open != 0) != 0) {  // wave-uniform: the step has unvisited vertices
+            // The sweep is latency-bound (PMC: waves wait ~90 % of their cycles on a chain of ~5 dependent loads per
+            // word), so the loads of all STEP_WORDS words are issued together, BRANCH-FREE: a lane with nothing to ask
+            // reads a harmless hot address instead of being masked off, which keeps the loads in one basic block where
+            // the compiler leaves them all in flight.
+            // ---- phase H1: adjacency heads (coalesced 8 bytes per lane and word)
+            int2 head[STEP_WORDS];
+            unsigned open_bits = 0;  // bit j: this lane's vertex of word j is unvisited
+#pragma unroll
+            for (int j = 0; j < STEP_WORDS; ++j) {
+                const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
+                const bool open = (open_mask >> lane) & 1ull;
+                open_bits |= static_cast<unsigned>(open) << j;
+                const long long v = (step * STEP_WORDS + j) * 64 + lane;
+                head[j] = a.d_inv_heads[open ? v : 0];
             }
-            // rows longer than the head continue in the CSR row from its third entry
-            bool more = open && parent < 0 && head.y >= 0;
-            if (__ballot(more) != 0) {
-                if (more) {
+            // ---- phase H2: first in-neighbour of every open vertex
+            bool hit[STEP_WORDS];
+#pragma unroll
+            for (int j = 0; j < STEP_WORDS; ++j) {
+                const bool ask = ((open_bits >> j) & 1u) && head[j].x >= 0;
+                hit[j] = in_frontier(ask ? head[j].x : 0) && ask;
+            }
+            VertexId parent[STEP_WORDS];
+            unsigned ask_y = 0;
+#pragma unroll
+            for (int j = 0; j < STEP_WORDS; ++j) {
+                parent[j] = hit[j] ? head[j].x : static_cast<VertexId>(-1);
+                if (((open_bits >> j) & 1u) && head[j].x >= 0 && !hit[j] && head[j].y >= 0) ask_y |= 1u << j;
+            }
+            // ---- phase H3: second in-neighbour, only where the first missed (skipped when no lane needs it)
+            unsigned more_bits = 0;  // bit j: continue in the CSR row
+            if (__ballot(ask_y != 0) != 0) {
+#pragma unroll
+                for (int j = 0; j < STEP_WORDS; ++j) {
+                    const bool ask = (ask_y >> j) & 1u;
+                    hit[j] = in_frontier(ask ? head[j].y : 0) && ask;
+                }
+#pragma unroll
+                for (int j = 0; j < STEP_WORDS; ++j) {
+                    if (hit[j]) parent[j] = head[j].y;
+                    if (((ask_y >> j) & 1u) && !hit[j]) more_bits |= 1u << j;
+                }
+            }
+
+            // ---- rows longer than the head continue in their CSR row from the third entry.  Only a few percent of the
+            //      vertices get here, but nearly every WORD has one: walking the words one after another would put ~3
+            //      dependent round trips per word back on the critical path.  Instead every lane takes ITS OWN next
+            //      pending vertex (whatever word it sits in), so all pending vertices of the step advance together and
+            //      the loop runs max-over-lanes(pending) times -- 1 or 2.
+            while (__ballot(more_bits != 0) != 0) {  // wave-uniform
+                const bool active = more_bits != 0;
+                const int jl = active ? (__ffs(more_bits) - 1) : 0;
+                more_bits &= more_bits - 1;
+                const VertexId v = static_cast<VertexId>((step * STEP_WORDS + jl) * 64 + lane);
+                SizeT pos = 0, end = 0;
+                VertexId p_found = -1;
+                if (active) {
                     pos = a.d_inv_row_offsets[v] + 2;
                     end = a.d_inv_row_offsets[v + 1];
                 }
                 // phase B: PROBE edges at a time, loads in flight together, up to SOLO_LIMIT edges per lane
                 for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
-                    if (__ballot(more && parent < 0 && pos < end) == 0) break;  // wave-uniform
+                    if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
                     VertexId nb[PROBE];
                     bool fw[PROBE];
-                    if (more && parent < 0 && pos + PROBE <= end && PROBE == 4) {
+                    if (active && p_found < 0 && pos + PROBE <= end && PROBE == 4) {
                         const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + pos);  // one 16-byte load
 #pragma unroll
                         for (int k = 0; k < PROBE; ++k) nb[k] = q.v[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < PROBE; ++k)
-                            nb[k] = (more && parent < 0 && pos + k < end) ? a.d_inv_column_indices[pos + k] : static_cast<VertexId>(-1);
+                            nb[k] = (active && p_found < 0 && pos + k < end) ? a.d_inv_column_indices[pos + k] : static_cast<VertexId>(-1);
                     }
 #pragma unroll
                     for (int k = 0; k < PROBE; ++k) fw[k] = (nb[k] >= 0) ? in_frontier(nb[k]) : false;
 #pragma unroll
                     for (int k = 0; k < PROBE; ++k)
-                        if (parent < 0 && fw[k]) parent = nb[k];
+                        if (p_found < 0 && fw[k]) p_found = nb[k];
                     pos += PROBE;
                 }
                 // phase C: rows still unresolved are swept by the whole wave, 64 in-edges per step
-                unsigned long long todo = __ballot(more && parent < 0 && pos < end);
+                unsigned long long todo = __ballot(active && p_found < 0 && pos < end);
                 while (todo) {
                     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
                     SizeT p = __shfl(pos, leader, util::kWaveSize);
@@ -203,31 +238,46 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                         const SizeT mine = p + static_cast<SizeT>(lane);
                         VertexId u = -1;
                         if (mine < e) u = a.d_inv_column_indices[mine];
-                        bool hit = false;
-                        if (u >= 0) hit = in_frontier(u);
-                        const unsigned long long hm = __ballot(hit);
+                        bool h = false;
+                        if (u >= 0) h = in_frontier(u);
+                        const unsigned long long hm = __ballot(h);
                         if (hm) {
                             hit_parent = __shfl(u, __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
                             break;
                         }
                     }
                     if (static_cast<int>(lane) == leader) {
-                        parent = hit_parent;
+                        p_found = hit_parent;
                         pos = end;
                     }
                     todo &= todo - 1;
                 }
+                const bool late = active && p_found >= 0;
+                if (late) {
+                    slice.d_labels[v] = new_label;
+                    if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = p_found;
+                    found_count += 1;
+                }
+#pragma unroll
+                for (int j = 0; j < STEP_WORDS; ++j) {  // fold the late discoveries into their words' result masks
+                    const unsigned long long fm = __ballot(late && jl == j);
+                    if (static_cast<int>(lane) == j) my_found |= fm;
+                }
             }
 
-            const bool found = open && parent >= 0;
-            if (found) {
-                slice.d_labels[v] = new_label;
-                if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
-                found_count += 1;
-                found_edges += static_cast<unsigned>(a.d_inv_row_offsets[v + 1] - a.d_inv_row_offsets[v]);
+            // ---- record the discoveries: labels (consecutive lanes = consecutive vertices) and the bitmap words
+#pragma unroll
+            for (int j = 0; j < STEP_WORDS; ++j) {
+                const bool found = parent[j] >= 0;
+                if (found) {
+                    const VertexId v = static_cast<VertexId>((step * STEP_WORDS + j) * 64 + lane);
+                    slice.d_labels[v] = new_label;
+                    if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent[j];
+                    found_count += 1;
+                }
+                const unsigned long long fm = __ballot(found);
+                if (static_cast<int>(lane) == j) my_found |= fm;
             }
-            const unsigned long long fm = __ballot(found);
-            if (static_cast<int>(lane) == j) my_found = fm;
         }
         if (owns_word) {  // coalesced write-back of the step's words
             a.d_frontier_out[my_word] = my_found;
