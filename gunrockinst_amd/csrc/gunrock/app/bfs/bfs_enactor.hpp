@@ -57,6 +57,10 @@ class BFSEnactor : public EnactorBase {
     // Load-balanced advance policy: 256 threads x 8 slots = 2048 edge slots per tile, 37 KB LDS,
     // 4 workgroups (16 waves) per CU.
     typedef oprtr::advance::KernelPolicy<256, 8, 4, oprtr::advance::LB> LBAdvancePolicy;
+    // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
+    typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
+    static constexpr int kTailEdgeLimit = 32768;
+    static constexpr int kTailMaxLevels = 4096;
 
     // traversal_mode: 0 = load-balanced top-down advance (reference default, bfs_enactor.cuh:581-697);
     //                 1 = reserved for the TWC advance (falls back to LB);
@@ -70,6 +74,46 @@ class BFSEnactor : public EnactorBase {
     }
 
    protected:
+    // Launch the multi-level tail kernel on queue[selector] (its length lives in ring slot iteration & 3), wait, and
+    // bring the host's view (iteration, selector, frontier size, statistics) up to date.
+    template <typename BFSProblem, typename BfsFunctor>
+    hipError_t RunTail(BFSProblem *problem, long long &iteration, int &selector, unsigned &queue_length, unsigned &queue_edges,
+                       long long &unexplored_edges, hipStream_t stream)
+    {
+        typedef typename BFSProblem::VertexId VertexId;
+        typedef typename BFSProblem::SizeT SizeT;
+        typedef typename BFSProblem::Value Value;
+        hipError_t retval = hipSuccess;
+        GraphSlice<VertexId, SizeT, Value> *gs = problem->graph_slices[0];
+        oprtr::advance::TailArgs<VertexId, SizeT> t;
+        t.queue[0] = gs->frontier_queues[0];
+        t.queue[1] = gs->frontier_queues[1];
+        t.selector = selector;
+        t.first_iteration = iteration;
+        t.d_tail = work_progress.d_tail;
+        t.edge_limit = kTailEdgeLimit;
+        t.max_levels = kTailMaxLevels;
+        t.d_levels_done = work_progress.LevelsDone();
+        t.d_level_sums = work_progress.d_sums;
+        t.d_row_offsets = gs->d_row_offsets;
+        t.d_column_indices = gs->d_column_indices;
+        t.d_overflow = work_progress.d_overflow;
+        if ((retval = oprtr::advance::LaunchTailLevels<TailPolicy, BFSProblem, BfsFunctor>(t, *problem->data_slices[0], stream)))
+            return retval;
+        if (INSTRUMENT && (retval = InstrumentEnd(stream))) return retval;
+        if ((retval = work_progress.GetAll(stream))) return retval;
+        const int done = work_progress.HostLevelsDone();
+        iteration += done;
+        selector ^= (done & 1);
+        queue_length = util::TailCount(work_progress.h_tail[iteration & 3]);
+        queue_edges = util::TailEdges(work_progress.h_tail[iteration & 3]);
+        // the loop head already counted the first level's frontier; add the rest
+        enactor_stats.total_queued += static_cast<long long>(work_progress.h_sums[0]);
+        enactor_stats.total_edges_queued += static_cast<long long>(work_progress.h_sums[1]);
+        unexplored_edges -= static_cast<long long>(work_progress.h_sums[1]);
+        return retval;
+    }
+
     template <typename AdvancePolicy, typename BFSProblem>
     hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size, bool dobfs)
     {
@@ -97,12 +141,11 @@ class BFSEnactor : public EnactorBase {
         long long unexplored_edges = problem->edges;
         // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])
         bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
+        bool snapshot_valid = true;  // d_frontier_mask[1] holds "visited before the last top-down level" (Reset seeds it)
         int cur_mask = 0;
         int selector = 0;
         long long iteration = 0;
         while (queue_length > 0) {
-            enactor_stats.total_queued += queue_length;
-            enactor_stats.total_edges_queued += queue_edges;
             const unsigned in_len = queue_length, in_edges = queue_edges;
             if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
 
@@ -111,8 +154,18 @@ class BFSEnactor : public EnactorBase {
             if (dobfs && !bottom_up &&
                 static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges)) {
                 // queue -> bitmap: the frontier is exactly what the last top-down level added to the visited bitmap
-                // (zero-degree discoveries included: they have no out-edges, so nobody can adopt them as parent)
-                {
+                // (zero-degree discoveries included: they have no out-edges, so nobody can adopt them as parent).
+                // After a multi-level tail run the snapshot is several levels old: rebuild from the queue instead.
+                if (!snapshot_valid) {
+                    if ((retval = util::GRError(hipMemsetAsync(ds->d_frontier_mask[0], 0, mask_bytes, stream),
+                                                "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
+                        break;
+                    hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
+                                       stream, gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length),
+                                       ds->d_frontier_mask[0]);
+                    if ((retval = util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__))) break;
+                    cur_mask = 0;
+                } else {
                     const long long words64 = static_cast<long long>(problem->MaskWords()) / 2;
                     hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(conv_grid), dim3(256), 0, stream,
                                        reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
@@ -124,21 +177,37 @@ class BFSEnactor : public EnactorBase {
                 bottom_up = true;
             } else if (dobfs && bottom_up &&
                        static_cast<double>(queue_length) * problem->beta < static_cast<double>(problem->nodes)) {
-                // bitmap -> queue (exact forward degrees; zero out-degree vertices are dropped)
-                if ((retval = work_progress.ClearAux(stream))) break;
+                // bitmap -> queue (exact forward degrees; zero out-degree vertices are dropped), written straight into
+                // this iteration's ring slot so the multi-level tail kernel can take over without a host round trip
+                unsigned long long *slot = work_progress.d_tail + (iteration & 3);
+                if ((retval = util::GRError(hipMemsetAsync(slot, 0, sizeof(unsigned long long), stream),
+                                            "BFSEnactor clear tail failed", __FILE__, __LINE__)))
+                    break;
                 hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256),
                                    0, stream, ds->d_frontier_mask[cur_mask], problem->nodes,
-                                   gs->frontier_queues[selector], work_progress.AuxTail(), work_progress.d_overflow,
-                                   gs->d_row_offsets);
+                                   gs->frontier_queues[selector], slot, work_progress.d_overflow, gs->d_row_offsets);
                 if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
-                if ((retval = work_progress.GetAux(queue_length, queue_edges, stream))) break;
                 bottom_up = false;
-                if (queue_length == 0) {  // nothing left that can expand
-                    if (INSTRUMENT) { InstrumentEnd(stream); hipStreamSynchronize(stream); InstrumentCollect(in_len, in_edges, 2); }
+                snapshot_valid = false;
+                if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
+                                                              unexplored_edges, stream)))
                     break;
-                }
+                if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 2);
+                continue;  // the loop re-examines the frontier the tail kernel left (empty, or too large for it)
+            } else if (!bottom_up && queue_edges <= static_cast<unsigned>(kTailEdgeLimit)) {
+                // small top-down frontier: run as many levels as stay small inside one launch
+                const long long before = iteration;
+                snapshot_valid = false;
+                if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
+                                                              unexplored_edges, stream)))
+                    break;
+                if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 3);
+                if (iteration != before) continue;
+                if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;  // no level ran: fall through to the grid kernel
             }
-            unexplored_edges -= in_edges;
+            enactor_stats.total_queued += queue_length;
+            enactor_stats.total_edges_queued += queue_edges;
+            unexplored_edges -= queue_edges;
             ds->iteration = static_cast<VertexId>(iteration);
             if (dobfs && !bottom_up) {
                 // snapshot of the visited bitmap before this top-down level (n/8 bytes, device to device)
@@ -146,6 +215,7 @@ class BFSEnactor : public EnactorBase {
                                                            hipMemcpyDeviceToDevice, stream),
                                             "BFSEnactor visited snapshot failed", __FILE__, __LINE__)))
                     break;
+                snapshot_valid = true;
             }
 
             if (bottom_up) {

@@ -78,12 +78,38 @@ struct AdvanceArgs {
     int *d_overflow;
 };
 
+// Frontier-array load.  FRESH = the arrays were written earlier in the SAME launch (multi-level tail kernel): read
+// them at agent scope (global_load sc1, served by L2) so a line this CU's L1 cached on an earlier level cannot come
+// back stale.
+template <bool FRESH, typename T>
+__device__ __forceinline__ T LoadQueue(const T *p)
+{
+    if (FRESH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <typename KernelPolicy, typename VertexId, typename SizeT>
+struct AdvanceShared {
+    typedef FrontierWriter<KernelPolicy::THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
+    SizeT scan[KernelPolicy::TILE];       // degree prefix relative to the tile's first slot
+    SizeT row[KernelPolicy::TILE];        // first edge of the staged vertex
+    VertexId vertex[KernelPolicy::TILE];  // staged vertex id
+    typename Writer::Storage writer;
+    int advance;                          // how far the frontier cursor moves after a tile
+    int owner_count[2][KernelPolicy::THREADS / util::kWaveSize];
+    unsigned long long level_tail;        // tail kernel: broadcast of the level's packed tail
+};
+
+// Expand the edge-slot tiles [tile_begin, tile_end) of the input frontier.  Whole workgroup calls; requires the writer
+// initialised and a barrier since.  On return all appends are complete and a barrier has passed (count is stable);
+// nothing has been flushed beyond what overflow protection forced.
 // OUT_WITH_DEGREES: the output is a full frontier (vertex, row start, degree prefix) ready for the next advance
 // (BFS); false = ids only, for outputs that pass through a filter / priority-queue split first (SSSP).
-template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
-__global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
-    AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a,
-    typename ProblemData::DataSlice slice)
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH>
+__device__ __forceinline__ void ExpandTiles(
+    const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a, typename ProblemData::DataSlice &slice,
+    const long long tile_begin, const long long tile_end,
+    AdvanceShared<KernelPolicy, typename ProblemData::VertexId, typename ProblemData::SizeT> &sh)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
@@ -91,38 +117,21 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     constexpr int TILE = KernelPolicy::TILE;
     constexpr int ITEMS = KernelPolicy::ITEMS;
     typedef FrontierWriter<THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
-
-    __shared__ SizeT s_scan[TILE];       // degree prefix relative to the tile's first slot
-    __shared__ SizeT s_row[TILE];        // first edge of the staged vertex
-    __shared__ VertexId s_vertex[TILE];  // staged vertex id
-    __shared__ typename Writer::Storage s_writer;
-    __shared__ int s_advance;            // how far the frontier cursor moves after this tile
-    __shared__ int s_owner_count[2][THREADS / util::kWaveSize];
-
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
-    Writer::Init(s_writer);
-
     const long long total = a.in_edges;
-    const long long tiles = (total + TILE - 1) / TILE;
-    const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
-    const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
-    const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
-    if (tile_begin >= tile_end) return;  // workgroup-uniform, nothing staged
 
-    // Frontier cursor: largest i with scan[i] <= first slot of this workgroup (zero-degree vertices
-    // are never enqueued, so the prefix is strictly increasing and the owner is unique).
-    SizeT cursor;
-    {
+    // Frontier cursor: largest i with scan[i] <= first slot of this range (zero-degree vertices are never enqueued,
+    // so the prefix is strictly increasing and the owner is unique).
+    SizeT cursor = 0;
+    if (tile_begin > 0) {  // the range that starts at slot 0 starts at frontier entry 0: no search (every level of the tail kernel)
         const SizeT first_slot = static_cast<SizeT>(tile_begin * TILE);
         SizeT lo = 0, hi = a.in_len;  // invariant: scan[lo] <= first_slot < scan[hi] (scan[in_len] = total)
         while (hi - lo > 1) {
             const SizeT mid = lo + (hi - lo) / 2;
-            if (a.in.scan[mid] <= first_slot) lo = mid; else hi = mid;
+            if (LoadQueue<FRESH>(a.in.scan + mid) <= first_slot) lo = mid; else hi = mid;
         }
         cursor = lo;
     }
-    __syncthreads();  // s_writer.count initialised
 
     for (long long tile = tile_begin; tile < tile_end; ++tile) {
         const SizeT slot0 = static_cast<SizeT>(tile * TILE);
@@ -131,10 +140,10 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
         // Appends of the previous tile are complete (barrier at the end of the loop body / after the
         // cursor search); every thread reads the count here, before this tile's first barrier, and the
         // next Append comes after it.
-        const int pending = Writer::Count(s_writer);
+        const int pending = Writer::Count(sh.writer);
 
         // ---- stage the covering frontier slice, THREADS entries per round ----
-        // s_scan holds the prefix relative to the tile (negative for a row that began in an earlier
+        // sh.scan holds the prefix relative to the tile (negative for a row that began in an earlier
         // tile); entries past the slice keep their true value (>= slots), INT_MAX past the frontier.
         // `owners` counts the staged entries that own at least one slot of this tile (a prefix of the
         // staged entries, because the degree prefix is increasing).
@@ -144,26 +153,26 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
             const SizeT idx = cursor + base + tid;
             SizeT rel = INT_MAX;
             if (idx < a.in_len) {
-                rel = a.in.scan[idx] - slot0;
+                rel = LoadQueue<FRESH>(a.in.scan + idx) - slot0;
                 if (rel < slots) {
-                    s_row[base + tid] = a.in.row_start[idx];
-                    s_vertex[base + tid] = a.in.v[idx];
+                    sh.row[base + tid] = LoadQueue<FRESH>(a.in.row_start + idx);
+                    sh.vertex[base + tid] = LoadQueue<FRESH>(a.in.v + idx);
                 }
             }
-            s_scan[base + tid] = rel;
+            sh.scan[base + tid] = rel;
             const unsigned long long in_tile = __ballot(rel < slots);
-            if ((tid & (util::kWaveSize - 1)) == 0) s_owner_count[round & 1][tid / util::kWaveSize] = __popcll(in_tile);
+            if ((tid & (util::kWaveSize - 1)) == 0) sh.owner_count[round & 1][tid / util::kWaveSize] = __popcll(in_tile);
             __syncthreads();
             staged = base + THREADS;
             int here = 0;
 #pragma unroll
-            for (int w = 0; w < THREADS / util::kWaveSize; ++w) here += s_owner_count[round & 1][w];
+            for (int w = 0; w < THREADS / util::kWaveSize; ++w) here += sh.owner_count[round & 1][w];
             owners += here;
             if (here < THREADS) break;  // uniform: slice ended inside this round
         }
         if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
-            if (OUT_WITH_DEGREES) Writer::template Flush<true>(s_writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
-            else Writer::FlushIds(s_writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+            if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+            else Writer::FlushIds(sh.writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
         }
 
         // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
@@ -176,13 +185,13 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
         for (int k = 0; k < ITEMS; ++k) {  // owner search in LDS
             const int slot = k * THREADS + tid;
             live[k] = slot < slots;
-            int lo = 0, hi = owners;  // s_scan[lo] <= slot < s_scan[hi] (hi == owners: past the slice)
+            int lo = 0, hi = owners;  // sh.scan[lo] <= slot < sh.scan[hi] (hi == owners: past the slice)
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (s_scan[mid] <= slot) lo = mid; else hi = mid;
+                if (sh.scan[mid] <= slot) lo = mid; else hi = mid;
             }
-            edge[k] = s_row[lo] + (slot - s_scan[lo]);
-            src[k] = s_vertex[lo];
+            edge[k] = sh.row[lo] + (slot - sh.scan[lo]);
+            src[k] = sh.vertex[lo];
         }
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(-1);
@@ -201,37 +210,143 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
             }
         }
         {   // one LDS reservation per wave per tile
-            int pos = Writer::Reserve(s_writer, mine);
+            int pos = Writer::Reserve(sh.writer, mine);
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k)
-                if (live[k]) s_writer.buf[pos++] = dst[k];
+                if (live[k]) sh.writer.buf[pos++] = dst[k];
         }
 
         // ---- move the cursor to the owner of the next tile's first slot ----
-        // Degrees are >= 1, so s_scan[j] >= j for j >= 1 and TILE staged entries always cover the tile
+        // Degrees are >= 1, so sh.scan[j] >= j for j >= 1 and TILE staged entries always cover the tile
         // PROVIDED the cursor is exact.  The owner is the last staged entry with prefix <= slots; the one
         // case LDS cannot answer is a full stage of degree-1 rows, where the next entry decides.
         if (tid == 0) {
             int lo = 0, hi = staged;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (s_scan[mid] <= slots) lo = mid; else hi = mid;
+                if (sh.scan[mid] <= slots) lo = mid; else hi = mid;
             }
             if (lo == TILE - 1) {
                 const SizeT next = cursor + TILE;
-                if (next < a.in_len && a.in.scan[next] - slot0 == slots) lo = TILE;
+                if (next < a.in_len && LoadQueue<FRESH>(a.in.scan + next) - slot0 == slots) lo = TILE;
             }
-            s_advance = lo;
+            sh.advance = lo;
         }
         __syncthreads();
-        cursor += s_advance;
+        cursor += sh.advance;
     }
 
-    // final flush (barrier above: all appends complete, count is stable)
-    const int rest = Writer::Count(s_writer);
+}
+
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
+    AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a,
+    typename ProblemData::DataSlice slice)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT> Shared;
+    typedef typename Shared::Writer Writer;
+    __shared__ Shared sh;
+
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
+    Writer::Init(sh.writer);
+
+    const long long tiles = (static_cast<long long>(a.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
+    const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
+    const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
+    if (tile_begin >= tile_end) return;  // workgroup-uniform, nothing staged
+    __syncthreads();                     // writer count initialised
+
+    ExpandTiles<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, false>(a, slice, tile_begin, tile_end, sh);
+
+    // final flush (ExpandTiles ended on a barrier: all appends complete, count is stable)
+    const int rest = Writer::Count(sh.writer);
     __syncthreads();
-    if (OUT_WITH_DEGREES) Writer::template Flush<true>(s_writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
-    else Writer::FlushIds(s_writer, rest, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+    if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+    else Writer::FlushIds(sh.writer, rest, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+}
+
+// ---- multi-level tail: ONE workgroup runs consecutive BSP levels while the frontier stays small ----
+// A level of a few thousand edges costs ~10 us as a kernel plus a ~20 us host round trip for its length; the last
+// levels of an R-MAT search (and every level of a road network) are that small.  Here a single workgroup keeps
+// expanding level after level: the next frontier comes back through the same FrontierWriter, the level's packed tail
+// is read at agent scope, and the host is involved again only when the frontier is empty, outgrows `edge_limit`, or
+// `max_levels` levels have run.  Queue arrays written on one level are read on the next with L1-bypassing loads after
+// every wave has drained its stores (s_waitcnt vmcnt(0)) and the workgroup has met at a barrier.
+template <typename VertexId, typename SizeT>
+struct TailArgs {
+    util::Frontier<VertexId, SizeT> queue[2];
+    int selector;                      // queue[selector] is the input of the first level
+    long long first_iteration;         // BSP iteration number of the first level
+    unsigned long long *d_tail;        // ring of 4 packed tails; slot (iteration & 3) holds the input frontier's
+    SizeT edge_limit;                  // leave when a level has more edge slots than this
+    int max_levels;
+    int *d_levels_done;                // out: levels executed
+    unsigned long long *d_level_sums;  // out: [0] sum of frontier lengths, [1] sum of frontier edge counts over those levels
+    const SizeT *d_row_offsets;
+    const VertexId *d_column_indices;
+    int *d_overflow;
+};
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void TailLevelsKernel(
+    TailArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> t, typename ProblemData::DataSlice slice)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT> Shared;
+    typedef typename Shared::Writer Writer;
+    __shared__ Shared sh;
+
+    Writer::Init(sh.writer);
+    int selector = t.selector;
+    long long iteration = t.first_iteration;
+    int done = 0;
+    unsigned long long sum_len = 0, sum_edges = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            sh.level_tail = __hip_atomic_load(t.d_tail + (iteration & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(t.d_tail + ((iteration + 2) & 3), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned long long tail = sh.level_tail;
+        const SizeT len = static_cast<SizeT>(util::TailCount(tail));
+        const SizeT edges = static_cast<SizeT>(util::TailEdges(tail));
+        if (len == 0 || edges > t.edge_limit || done >= t.max_levels) break;  // workgroup-uniform
+
+        AdvanceArgs<VertexId, SizeT> a;
+        a.in = t.queue[selector];
+        a.out = t.queue[selector ^ 1];
+        a.in_len = len;
+        a.in_edges = edges;
+        a.d_row_offsets = t.d_row_offsets;
+        a.d_column_indices = t.d_column_indices;
+        a.d_tail_out = t.d_tail + ((iteration + 1) & 3);
+        a.d_tail_clear = nullptr;
+        a.d_overflow = t.d_overflow;
+        slice.iteration = static_cast<VertexId>(iteration);
+
+        const long long tiles = (static_cast<long long>(edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+        ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, 0, tiles, sh);
+        const int rest = Writer::Count(sh.writer);
+        __syncthreads();
+        Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+        // every wave's queue stores (and the flush's tail atomic) must have reached L2 before the next level reads them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        selector ^= 1;
+        ++iteration;
+        ++done;
+        sum_len += len;
+        sum_edges += edges;
+    }
+    if (threadIdx.x == 0) {
+        *t.d_levels_done = done;
+        t.d_level_sums[0] = sum_len;
+        t.d_level_sums[1] = sum_edges;
+    }
 }
 
 // Host-side launch.  Mirrors advance::LaunchKernel (advance/kernel.cuh:101-129) at the distilled level of
@@ -250,6 +365,15 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
     hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>), dim3(static_cast<unsigned>(grid)),
                        dim3(KernelPolicy::THREADS), 0, stream, args, slice);
     return util::GRError("advance::LoadBalancedKernel launch failed", __FILE__, __LINE__);
+}
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+hipError_t LaunchTailLevels(const TailArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
+                            const typename ProblemData::DataSlice &slice, hipStream_t stream)
+{
+    hipLaunchKernelGGL((TailLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(1), dim3(KernelPolicy::THREADS), 0, stream,
+                       args, slice);
+    return util::GRError("advance::TailLevelsKernel launch failed", __FILE__, __LINE__);
 }
 
 }  // namespace advance

@@ -41,10 +41,13 @@ __host__ __device__ __forceinline__ unsigned TailEdges(unsigned long long t) { r
 
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
-    static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail for frontier conversions
+    static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
+                                           // 7: spare; tail-kernel sums live in d_sums[2]
     static constexpr int kAux = 4;
     unsigned long long *d_tail = nullptr;  // [kSlots] packed (edges<<32 | vertices)
     int *d_overflow = nullptr;             // set when a writer ran out of queue capacity
+    unsigned long long *d_sums = nullptr;  // [2] tail kernel: summed frontier lengths / edges
+    unsigned long long *h_sums = nullptr;
     unsigned long long *h_tail = nullptr;  // pinned mirror for the per-step read-back
     int *h_overflow = nullptr;
 
@@ -57,6 +60,8 @@ struct WorkProgress {
         GR_CHECK(hipHostMalloc(&h_tail, sizeof(unsigned long long) * kSlots, hipHostMallocDefault),
                  "WorkProgress hipHostMalloc failed");
         GR_CHECK(hipHostMalloc(&h_overflow, sizeof(int), hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
+        GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
+        GR_CHECK(hipHostMalloc(&h_sums, sizeof(unsigned long long) * 2, hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
         return Reset(0);
     }
 
@@ -88,6 +93,20 @@ struct WorkProgress {
         edges = TailEdges(h_tail[slot & 3]);
         return retval;
     }
+
+    // One blocking read of the whole ring + the tail kernel's outputs.
+    hipError_t GetAll(hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemcpyAsync(h_tail, d_tail, sizeof(unsigned long long) * kSlots, hipMemcpyDeviceToHost, stream),
+                 "WorkProgress GetAll copy failed");
+        GR_CHECK(hipMemcpyAsync(h_sums, d_sums, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, stream),
+                 "WorkProgress GetAll copy failed");
+        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetAll sync failed");
+        return retval;
+    }
+    int *LevelsDone() { return reinterpret_cast<int *>(d_tail + 6); }
+    int HostLevelsDone() const { return *reinterpret_cast<const int *>(h_tail + 6); }
 
     unsigned long long *AuxTail() { return d_tail + kAux; }
     hipError_t ClearAux(hipStream_t stream)
@@ -122,6 +141,9 @@ struct WorkProgress {
         if (d_overflow) GRError(hipFree(d_overflow), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (h_tail) GRError(hipHostFree(h_tail), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
         if (h_overflow) GRError(hipHostFree(h_overflow), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        if (d_sums) GRError(hipFree(d_sums), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        if (h_sums) GRError(hipHostFree(h_sums), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        d_sums = nullptr; h_sums = nullptr;
         d_tail = nullptr; d_overflow = nullptr; h_tail = nullptr; h_overflow = nullptr;
     }
 };

@@ -129,7 +129,8 @@ def test_instrumented_run_reports_kernel_time():
     src, _ = o.highest_degree_node(g)
     labels, _, st, ms = _run(g, src, False, True, instrument=True)
     assert np.array_equal(labels, o.bfs(g, src)[0])
-    assert st["kernel_launches"] == st["search_depth"] and 0 < st["kernel_ms"] <= ms
+    # small consecutive levels share one launch (multi-level tail kernel), so launches <= levels
+    assert 0 < st["kernel_launches"] <= st["search_depth"] and 0 < st["kernel_ms"] <= ms
 
 
 def test_reset_and_rerun_same_problem():
