@@ -56,7 +56,7 @@ class BFSEnactor : public EnactorBase {
 
     // Load-balanced advance policy: 256 threads x 8 slots = 2048 edge slots per tile, 37 KB LDS,
     // 4 workgroups (16 waves) per CU.
-    typedef oprtr::advance::KernelPolicy<256, 8, 4, oprtr::advance::LB> LBAdvancePolicy;
+    typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> LBAdvancePolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
     static constexpr int kTailEdgeLimit = 32768;

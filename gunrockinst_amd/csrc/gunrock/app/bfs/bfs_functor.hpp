@@ -31,8 +31,12 @@ struct BFSFunctor {
     static __device__ __forceinline__ bool ScreenEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
                                                       VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-        const unsigned word = problem->d_visited_mask[static_cast<unsigned>(d_id) >> 5];
-        return (word & (1u << (d_id & 31))) == 0;        // stale-tolerant: a miss only costs an atomic
+        // L1-bypassing load (global_load sc1, served by the XCD's L2): a line parked in this CU's L1 is never refreshed
+        // during the launch, so hot words (hubs) would keep reading "unvisited" and every edge into a hub discovered on
+        // this level would pay a memory-side atomic -- measured: the heavy top-down levels were atomic-bound.
+        const unsigned word = __hip_atomic_load(problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        return (word & (1u << (d_id & 31))) == 0;        // still stale-tolerant: a miss only costs an atomic
     }
 
     static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
