@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6772)
     ap.add_argument("--cpu-baseline-runs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primitive", choices=["bfs", "cc", "sssp"], default="bfs",
+                    help="bfs = the headline metric (default); cc / sssp = BASELINE.json configs 4 / 3 on one GPU")
+    ap.add_argument("--delta-factor", type=int, default=16)
     ap.add_argument("--traversal-mode", type=int, default=2,
                     help="0 = load-balanced top-down only, 2 = direction-optimizing (default)")
     return ap.parse_args()
@@ -68,6 +71,10 @@ def main():
     if world > 1:
         from gunrockinst_amd import multi_gpu
         result = multi_gpu.bench(args, rank, world, local_rank)
+    elif args.primitive == "cc":
+        result = bench_cc(args, torch, ga, devgraph, local_rank)
+    elif args.primitive == "sssp":
+        result = bench_sssp(args, torch, ga, devgraph, local_rank)
     else:
         result = bench_single(args, torch, ga, devgraph, local_rank)
     if rank == 0:
@@ -206,6 +213,129 @@ def bench_single(args, torch, ga, devgraph, device_index):
         "parity_vs_oracle": parity,
         "roofline": roofline, "cpu_baseline": cpu,
     }
+
+
+def bench_cc(args, torch, ga, devgraph, device_index):
+    """BASELINE.json config 4: connected components on R-MAT (hook / pointer-jump filter loop), one GPU."""
+    n = 1 << args.scale
+    ro, ci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+    m = int(ci.shape[0])
+    p = ga.CcProblem(instrument=False, device=device_index).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    steps = max(1, min(args.steps, 10))
+    for _ in range(min(args.warmup, 2)):
+        p.reset(); p.enact()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enact_ms = 0.0
+    for _ in range(steps):
+        p.reset()
+        enact_ms += p.enact()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    st = p.stats()
+    ids = devgraph.as_tensor(p.device_results(), n)
+    components = int((ids == torch.arange(n, device=ids.device, dtype=torch.int32)).sum())
+    ip = ga.CcProblem(instrument=True, device=device_index).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    ip.reset(); ip.enact()
+    ist = ip.stats()
+    ip.close()
+    balg = st["edge_sweeps"] * 9.0 * m + st["vertex_sweeps"] * 8.0 * n          # SURVEY 8(d), sweeps of THIS run
+    achieved = balg / (ist["kernel_ms"] * 1e-3) / 1e9
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        from oracle import gr_oracle as o
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        g = o.Csr(n, h_ro, h_ci)
+        t0 = time.perf_counter()
+        ref, ref_count = o.cc(g)
+        cpu_s = time.perf_counter() - t0
+        got, _ = p.extract()
+        parity = bool((got == ref).all()) and ref_count == components
+        cpu = {"value": round(m / (cpu_s * 1e6), 2), "unit": "M edges/s", "cores": 1, "kind": "port",
+               "sample": "1 union-find pass (oracle restatement of Boost connected_components) over the same graph, %.1f s" % cpu_s}
+    p.close()
+    return {"metric": "CC R-MAT scale-%d: million edges per second of Enact (m / t)" % args.scale,
+            "value": round(m / (enact_ms / steps * 1e3), 2), "unit": "M edges/s", "n_gpus": 1, "steps": steps,
+            "warmup": min(args.warmup, 2), "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "CC hook/pointer-jump, R-MAT scale-%d: n=%d, m=%d; %d components; %d edge sweeps, %d vertex sweeps"
+                                   % (args.scale, n, m, components, st["edge_sweeps"], st["vertex_sweeps"])},
+            "enact_ms_per_step": round(enact_ms / steps, 4), "parity_vs_oracle": parity,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": "filter::ApplyKernel (hook / jump sweeps)",
+                         "launches": ist["kernel_launches"], "kernel_ms": round(ist["kernel_ms"], 4),
+                         "alg_bytes": balg},
+            "cpu_baseline": cpu}
+
+
+def bench_sssp(args, torch, ga, devgraph, device_index):
+    """BASELINE.json config 3 stand-in: soc-LiveJournal1 is not available offline, so R-MAT with seeded integer weights
+    in [1, 64]; delta-stepping advance with near/far pile."""
+    n = 1 << args.scale
+    ro, ci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+    m = int(ci.shape[0])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(args.seed)
+    w = torch.randint(1, 65, (m,), generator=gen, device="cuda", dtype=torch.int32)
+    deg = (ro[1:] - ro[:-1]).long()
+    avg_w, avg_d = float(w.double().mean()), float(int(deg.double().mean()))
+    delta = (int(avg_w) * 32.0 / max(avg_d, 1.0)) * args.delta_factor     # SSSPProblem::EstimatedDelta x delta_factor
+    src0, _ = devgraph.largest_degree_source(ro)
+    sources = [src0] + devgraph.seeded_sources(ro, 8, args.seed)
+    p = ga.SsspProblem(mark_pred=False, instrument=False, device=device_index)
+    p.init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+    steps = max(1, min(args.steps, len(sources)))
+    for k in range(min(args.warmup, 2)):
+        p.reset(sources[k % len(sources)]); p.enact(sources[k % len(sources)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enact_ms, relaxed = 0.0, 0
+    for k in range(steps):
+        s = sources[k % len(sources)]
+        p.reset(s)
+        enact_ms += p.enact(s)
+        relaxed += p.stats()["relaxed_edges"]
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ip = ga.SsspProblem(False, True, device_index)
+    ip.init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+    ip.reset(src0); ip.enact(src0)
+    ist = ip.stats()
+    ip.close()
+    cpu, parity, balg = None, None, None
+    if not args.no_cpu_baseline:
+        from oracle import gr_oracle as o
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        h_w = w.cpu().numpy().astype("uint32")
+        g = o.Csr(n, h_ro, h_ci)
+        t0 = time.perf_counter()
+        ref, _ = o.sssp(g, src0, h_w)
+        cpu_s = time.perf_counter() - t0
+        p.reset(src0); p.enact(src0)
+        got, _ = p.extract()
+        parity = bool((got == ref).all())
+        reach = ref != 0xFFFFFFFF
+        n_r = int(reach.sum())
+        m_r = int((h_ro[1:] - h_ro[:-1])[reach].sum())
+        balg = 8.0 * m_r + 20.0 * n_r                                         # SURVEY 8(d): oracle-needed work
+        cpu = {"value": round(m_r / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+               "sample": "1 heap-Dijkstra run (oracle restatement of Boost dijkstra_shortest_paths) from the max-degree source, %.1f s" % cpu_s}
+    p.close()
+    roof = None
+    if balg:
+        achieved = balg / (ist["kernel_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                "traffic": None, "kernel": "advance::LoadBalancedKernel<SSSPFunctor> + priority_queue::BisectKernel",
+                "launches": ist["kernel_launches"], "kernel_ms": round(ist["kernel_ms"], 4), "alg_bytes": balg,
+                "relaxed_edges_src0": ist["relaxed_edges"], "iterations_src0": ist["iterations"]}
+    return {"metric": "SSSP R-MAT scale-%d uniform weights [1,64]: MTEPS = edges of reached vertices / Enact time" % args.scale,
+            "value": round((m_r if balg else relaxed / steps) / (enact_ms / steps * 1e3), 2), "unit": "MTEPS", "n_gpus": 1,
+            "steps": steps, "warmup": min(args.warmup, 2), "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "uint32", "data": "synthetic",
+            "config": {"workload": "SSSP delta-stepping (near/far), R-MAT scale-%d: n=%d, m=%d, weights uniform int [1,64] seed 0x%x, "
+                                   "delta_factor %d (delta %.1f); soc-LiveJournal1 unavailable offline"
+                                   % (args.scale, n, m, args.seed, args.delta_factor, delta)},
+            "enact_ms_per_step": round(enact_ms / steps, 4), "parity_vs_oracle": parity, "roofline": roof, "cpu_baseline": cpu}
 
 
 if __name__ == "__main__":

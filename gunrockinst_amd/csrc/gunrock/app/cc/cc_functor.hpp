@@ -4,8 +4,12 @@
 // `node` is an EDGE id for the hook functors and a VERTEX id for the others.  All writes store a strictly
 // smaller id into a larger slot, so component_ids[v] <= v always holds and the smallest vertex of a component
 // is never overwritten: the fixed point is component_ids[v] = min id of v's component for any interleaving
-// (SURVEY 8(a) C3).  Reads that race with other lanes' writes go through agent-scope relaxed loads so a sweep
-// sees hooks made earlier in the same launch where the hardware allows; correctness never depends on it.
+// (SURVEY 8(a) C3).  All accesses are PLAIN loads and stores: a sweep may read values that other lanes have already
+// replaced (per-XCD L2s and per-CU L1s are not coherent inside a launch) -- that only delays convergence, because every
+// value ever stored in component_ids[v] is an id of v's component not larger than v, and the convergence flags are
+// re-evaluated by the next launch on fresh data.  Measured at scale-24: write-through (sc1) stores of the two flag
+// words from millions of lanes serialised at the memory side and made a sweep ~40x slower than its traffic; plain
+// stores collapse in the write-back L2.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,12 +21,12 @@ namespace cc {
 template <typename T>
 __device__ __forceinline__ T LoadFresh(const T *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
 }
 template <typename T>
 __device__ __forceinline__ void StoreFresh(T *p, T v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *p = v;
 }
 
 // mask[v] = (v is its own parent) ? 0 : 1      -- cc_functor.cuh:30-47
