@@ -83,6 +83,7 @@ _SIGNATURES = {
     "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
     "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "grx_bfs_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
@@ -276,6 +277,10 @@ class BfsProblem:
         """Enable traversal_mode=2 (direction-optimizing).  No arguments = the graph is symmetric."""
         _check(lib().grx_bfs_set_inverse_graph(self._h, C.c_void_p(d_inv_row_offsets), C.c_void_p(d_inv_col_indices),
                                                alpha, beta), "BFSProblem::SetInverseGraph")
+        return self
+
+    def set_tuning(self, alpha=0.0, beta=0.0, lite_factor=-1.0, tail_edge_limit=-1):
+        _check(lib().grx_bfs_set_tuning(self._h, alpha, beta, lite_factor, tail_edge_limit), "grx_bfs_set_tuning")
         return self
 
     def reset(self, src, queue_sizing=1.0):

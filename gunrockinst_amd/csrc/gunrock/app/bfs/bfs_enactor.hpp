@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <gunrock/app/bfs/bfs_functor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
@@ -91,7 +92,7 @@ class BFSEnactor : public EnactorBase {
         t.selector = selector;
         t.first_iteration = iteration;
         t.d_tail = work_progress.d_tail;
-        t.edge_limit = kTailEdgeLimit;
+        t.edge_limit = problem->tail_edge_limit;
         t.max_levels = kTailMaxLevels;
         t.d_levels_done = work_progress.LevelsDone();
         t.d_level_sums = work_progress.d_sums;
@@ -141,6 +142,7 @@ class BFSEnactor : public EnactorBase {
         long long unexplored_edges = problem->edges;
         // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])
         bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
+        bool force_bottom_up = false; // the last level ran count-only: its output exists only as a bitmap (already built)
         bool snapshot_valid = true;  // d_frontier_mask[1] holds "visited before the last top-down level" (Reset seeds it)
         int cur_mask = 0;
         int selector = 0;
@@ -152,7 +154,11 @@ class BFSEnactor : public EnactorBase {
             // ---- direction choice (Beamer's edge rule for down->up, the reference's vertex rule for up->down,
             //      dobfs_enactor.cuh:397,569) ----
             if (dobfs && !bottom_up &&
-                static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges)) {
+                (force_bottom_up || static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges))) {
+                if (force_bottom_up) {  // the count-only level already left its discoveries in d_frontier_mask[0]
+                    force_bottom_up = false;
+                    cur_mask = 0;
+                } else
                 // queue -> bitmap: the frontier is exactly what the last top-down level added to the visited bitmap
                 // (zero-degree discoveries included: they have no out-edges, so nobody can adopt them as parent).
                 // After a multi-level tail run the snapshot is several levels old: rebuild from the queue instead.
@@ -194,7 +200,7 @@ class BFSEnactor : public EnactorBase {
                     break;
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 2);
                 continue;  // the loop re-examines the frontier the tail kernel left (empty, or too large for it)
-            } else if (!bottom_up && queue_edges <= static_cast<unsigned>(kTailEdgeLimit)) {
+            } else if (!bottom_up && queue_edges <= static_cast<unsigned>(problem->tail_edge_limit)) {
                 // small top-down frontier: run as many levels as stay small inside one launch
                 const long long before = iteration;
                 snapshot_valid = false;
@@ -250,6 +256,36 @@ class BFSEnactor : public EnactorBase {
                 args.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
                 args.d_overflow = work_progress.d_overflow;
+                // "Count-only" top-down level: when the search is about to turn bottom-up, the level's discoveries are needed
+                // only as a bitmap (visited now XOR visited before), so the frontier writer (row-offset gather, 12-byte queue
+                // entries) and the scattered label stores are skipped; the bottom-up sweep that follows labels them in order.
+                const bool lite = dobfs && snapshot_valid && queue_edges > static_cast<unsigned>(problem->tail_edge_limit) &&
+                                  static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges);
+                if (lite) {
+                    ds->lite = 1;
+                    args.d_tail_out = work_progress.AuxTail();  // the advance's own count includes duplicates: discarded
+                    retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor, true, true>(
+                        args, *ds, max_grid_size, stream, oprtr::advance::V2V);
+                    ds->lite = 0;
+                    if (retval) break;
+                    const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
+                    long long fgrid = (words64 + 3) / 4;
+                    if (fgrid > cu_count * 8) fgrid = cu_count * 8;
+                    hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
+                                       stream, ds->d_fresh, static_cast<long long>(problem->nodes),
+                                       reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
+                                       reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
+                                       reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), ds->d_labels,
+                                       static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3));
+                    if ((retval = util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__))) break;
+                    cur_mask = 0;
+                    force_bottom_up = true;
+                    if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
+                    ++iteration;
+                    if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+                    if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 4);
+                    continue;  // (selector unchanged: no queue was written)
+                }
                 if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
                          args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;

@@ -42,6 +42,14 @@ struct BFSFunctor {
     static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
                                                     VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
+        if (problem->lite) {
+            // count-only level (oprtr/advance/bottom_up.hpp FreshToBitmapKernel): every edge into an unvisited vertex may
+            // "discover" it -- all sources of one level are equally valid parents -- so a plain byte store replaces the claim
+            // (A best-effort same-level filter in the bitmap -- plain byte read-modify-write, the reference's bitmask cull,
+            //  filter/cta.cuh:196-201 -- was measured too: it cost more than the duplicate byte stores it saved.)
+            problem->d_fresh[d_id] = 1;
+            return true;
+        }
         unsigned *word = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
         const unsigned bit = 1u << (d_id & 31);
         return (atomicOr(word, bit) & bit) == 0;          // exactly one winner per vertex
@@ -50,7 +58,7 @@ struct BFSFunctor {
     static __device__ __forceinline__ void ApplyEdge(VertexId s_id, VertexId d_id, DataSlice *problem,
                                                      VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-        problem->d_labels[d_id] = problem->iteration + 1;
+        if (!problem->lite) problem->d_labels[d_id] = problem->iteration + 1;  // (lite: FreshToBitmapKernel labels in vertex order)
         if (ProblemData::MARK_PREDECESSORS) problem->d_preds[d_id] = s_id;
     }
 

@@ -102,6 +102,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         VertexId *d_preds = nullptr;          // parent per vertex (-2 unset, -1 source)
         unsigned *d_visited_mask = nullptr;   // 1 bit per vertex
         VertexId iteration = 0;               // current BSP level (labels written = iteration + 1)
+        int lite = 0;                         // 1: count-only level: mark d_fresh[d] with a plain byte store, no claim, no label
+        unsigned char *d_fresh = nullptr;     // one byte per vertex, all zero between levels (direction-optimizing only)
         // direction-optimizing traversal (reference app/dobfs: d_frontier_map_in/out, dobfs_problem.cuh):
         unsigned *d_frontier_mask[2] = {nullptr, nullptr};  // 1 bit per vertex: current / next frontier
         unsigned *d_never_mask = nullptr;                   // vertices without in-edges: nothing can ever discover them
@@ -114,6 +116,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     bool direction_optimizing = false;
     float alpha = 14.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges
     float beta = 24.0f;   // bottom-up -> top-down when frontier_vertices * beta < nodes
+    float lite_factor = 8.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
+    int tail_edge_limit = 32768;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 
     DataSlice **data_slices = nullptr;  // host copies (by-value kernel arguments), one per GPU
     DataSlice **d_data_slices = nullptr;  // kept for source compatibility; unused (no device-side struct)
@@ -131,6 +135,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                 for (int i = 0; i < 2; ++i)
                     if (ds->d_frontier_mask[i]) util::GRError(hipFree(ds->d_frontier_mask[i]), "BFSProblem hipFree d_frontier_mask failed", __FILE__, __LINE__);
                 if (ds->d_never_mask) util::GRError(hipFree(ds->d_never_mask), "BFSProblem hipFree d_never_mask failed", __FILE__, __LINE__);
+                if (ds->d_fresh) util::GRError(hipFree(ds->d_fresh), "BFSProblem hipFree d_fresh failed", __FILE__, __LINE__);
                 if (ds->d_inv_heads) util::GRError(hipFree(ds->d_inv_heads), "BFSProblem hipFree d_inv_heads failed", __FILE__, __LINE__);
                 delete ds;
             }
@@ -161,6 +166,11 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (!ds->d_never_mask)
             GR_CHECK(hipMalloc(&ds->d_never_mask, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
                      "BFSProblem hipMalloc d_never_mask failed");
+        if (!ds->d_fresh) {
+            const size_t bytes = (static_cast<size_t>(this->nodes) + 255) / 256 * 256 + 256;
+            GR_CHECK(hipMalloc(&ds->d_fresh, bytes), "BFSProblem hipMalloc d_fresh failed");
+            GR_CHECK(hipMemset(ds->d_fresh, 0, bytes), "BFSProblem hipMemset d_fresh failed");  // levels leave it zero again
+        }
         if (!ds->d_inv_heads)
             GR_CHECK(hipMalloc(&ds->d_inv_heads, sizeof(int2) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)),
                      "BFSProblem hipMalloc d_inv_heads failed");

@@ -51,6 +51,39 @@ __global__ inline void BitmapDiffKernel(const unsigned long long *d_now, const u
         d_out[w] = d_now[w] ^ d_before[w];
 }
 
+// ---- "fresh" byte flags -> bitmaps + labels (the closing pass of an atomic-free top-down level) ----
+// A count-only top-down level marks every unvisited destination with a plain one-byte store (duplicates are harmless,
+// nothing waits for a returned value; the same level with atomicOr claims was bound by the memory-side atomic rate).
+// This pass owns 64 consecutive vertices per wave: it turns the bytes into the next-frontier word, ORs them into the
+// visited word, writes the labels in vertex order, clears the bytes and counts the discoveries.
+template <typename VertexId>
+__global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, unsigned long long *d_visited,
+                                    const unsigned long long *d_visited_before, unsigned long long *d_frontier_out,
+                                    VertexId *d_labels, VertexId label, unsigned long long *d_tail_out)
+{
+    const unsigned lane = util::LaneId();
+    const long long words = (nodes + 63) / 64;
+    const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize;
+    const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
+    unsigned count = 0;
+    for (long long w = wave0; w < words; w += nwaves) {
+        const long long v = w * 64 + lane;
+        const bool fresh = v < nodes && d_fresh[v] != 0;
+        // "seen" is the bitmap as it was BEFORE the level: the level's own best-effort filter bits in d_visited are a
+        // subset of the discoveries and must not mask them
+        const unsigned long long seen = d_visited_before[w];  // wave-uniform
+        const unsigned long long mask = __ballot(fresh) & ~seen;
+        if (fresh) d_fresh[v] = 0;
+        if ((mask >> lane) & 1ull) d_labels[v] = label;
+        if (lane == 0) {
+            d_frontier_out[w] = mask;
+            d_visited[w] = seen | mask;  // authoritative: repairs whatever the racy filter lost
+            count += static_cast<unsigned>(__popcll(mask));
+        }
+    }
+    if (lane == 0 && count) atomicAdd(d_tail_out, static_cast<unsigned long long>(count));
+}
+
 // Frontier membership tests for the bottom-up sweep.
 // BitmapLookup: one bitmap indexed by vertex id (single GPU).
 // StripedBitmapLookup: vertex-cut over P ranks, owner = v mod P, local id = v div P (the reference's only multi-GPU
@@ -211,10 +244,13 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                     if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
                     VertexId nb[PROBE];
                     bool fw[PROBE];
-                    if (active && p_found < 0 && pos + PROBE <= end && PROBE == 4) {
-                        const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + pos);  // one 16-byte load
+                    if (active && p_found < 0 && pos + PROBE <= end && (PROBE % 4) == 0) {
 #pragma unroll
-                        for (int k = 0; k < PROBE; ++k) nb[k] = q.v[k];
+                        for (int qd = 0; qd < PROBE / 4; ++qd) {  // 16-byte loads (rows are 4-byte aligned: gfx950 takes that)
+                            const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + pos + 4 * qd);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) nb[4 * qd + k] = q.v[k];
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < PROBE; ++k)
@@ -234,16 +270,20 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                     SizeT p = __shfl(pos, leader, util::kWaveSize);
                     const SizeT e = __shfl(end, leader, util::kWaveSize);
                     VertexId hit_parent = -1;
-                    for (; p < e; p += util::kWaveSize) {
-                        const SizeT mine = p + static_cast<SizeT>(lane);
-                        VertexId u = -1;
-                        if (mine < e) u = a.d_inv_column_indices[mine];
-                        bool h = false;
-                        if (u >= 0) h = in_frontier(u);
-                        const unsigned long long hm = __ballot(h);
-                        if (hm) {
-                            hit_parent = __shfl(u, __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
-                            break;
+                    for (; p < e && hit_parent < 0; p += 4 * util::kWaveSize) {  // 256 in-edges per step, 4 loads in flight per lane
+                        VertexId u[4];
+                        bool h[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const SizeT mine = p + static_cast<SizeT>(k * util::kWaveSize + lane);
+                            u[k] = (mine < e) ? a.d_inv_column_indices[mine] : static_cast<VertexId>(-1);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) h[k] = (u[k] >= 0) ? in_frontier(u[k]) : false;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long hm = __ballot(h[k]);
+                            if (hm && hit_parent < 0) hit_parent = __shfl(u[k], __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
                         }
                     }
                     if (static_cast<int>(lane) == leader) {

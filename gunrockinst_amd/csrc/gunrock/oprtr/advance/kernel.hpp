@@ -98,6 +98,7 @@ struct AdvanceShared {
     int advance;                          // how far the frontier cursor moves after a tile
     int owner_count[2][KernelPolicy::THREADS / util::kWaveSize];
     unsigned long long level_tail;        // tail kernel: broadcast of the level's packed tail
+    unsigned long long wave_sum[KernelPolicy::THREADS / util::kWaveSize];  // COUNT_ONLY reduction
 };
 
 // Expand the edge-slot tiles [tile_begin, tile_end) of the input frontier.  Whole workgroup calls; requires the writer
@@ -105,11 +106,13 @@ struct AdvanceShared {
 // nothing has been flushed beyond what overflow protection forced.
 // OUT_WITH_DEGREES: the output is a full frontier (vertex, row start, degree prefix) ready for the next advance
 // (BFS); false = ids only, for outputs that pass through a filter / priority-queue split first (SSSP).
-template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH>
+// COUNT_ONLY: accepted destinations are only counted (into `accepted`), nothing is enqueued -- for a level whose output
+// frontier will be consumed as a bitmap (the bottom-up direction) and needs neither ids nor degrees.
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH, bool COUNT_ONLY = false>
 __device__ __forceinline__ void ExpandTiles(
     const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a, typename ProblemData::DataSlice &slice,
     const long long tile_begin, const long long tile_end,
-    AdvanceShared<KernelPolicy, typename ProblemData::VertexId, typename ProblemData::SizeT> &sh)
+    AdvanceShared<KernelPolicy, typename ProblemData::VertexId, typename ProblemData::SizeT> &sh, unsigned &accepted)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
@@ -170,7 +173,7 @@ __device__ __forceinline__ void ExpandTiles(
             owners += here;
             if (here < THREADS) break;  // uniform: slice ended inside this round
         }
-        if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
+        if (!COUNT_ONLY && pending > KernelPolicy::STAGE_CAPACITY - TILE) {
             if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
             else Writer::FlushIds(sh.writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
         }
@@ -209,7 +212,8 @@ __device__ __forceinline__ void ExpandTiles(
                 ++mine;
             }
         }
-        {   // one LDS reservation per wave per tile
+        accepted += static_cast<unsigned>(mine);
+        if (!COUNT_ONLY) {  // one LDS reservation per wave per tile
             int pos = Writer::Reserve(sh.writer, mine);
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k)
@@ -238,7 +242,7 @@ __device__ __forceinline__ void ExpandTiles(
 
 }
 
-template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true, bool COUNT_ONLY = false>
 __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a,
     typename ProblemData::DataSlice slice)
@@ -259,8 +263,21 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     if (tile_begin >= tile_end) return;  // workgroup-uniform, nothing staged
     __syncthreads();                     // writer count initialised
 
-    ExpandTiles<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, false>(a, slice, tile_begin, tile_end, sh);
+    unsigned accepted = 0;
+    ExpandTiles<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, false, COUNT_ONLY>(a, slice, tile_begin, tile_end, sh, accepted);
 
+    if (COUNT_ONLY) {  // workgroup total -> one atomic on the packed tail (edge half stays 0)
+        unsigned long long sum = util::WaveSum(static_cast<unsigned long long>(accepted));
+        if ((threadIdx.x & (util::kWaveSize - 1)) == 0) sh.wave_sum[threadIdx.x / util::kWaveSize] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long total = 0;
+#pragma unroll
+            for (int w = 0; w < KernelPolicy::THREADS / util::kWaveSize; ++w) total += sh.wave_sum[w];
+            if (total) atomicAdd(a.d_tail_out, total);
+        }
+        return;
+    }
     // final flush (ExpandTiles ended on a barrier: all appends complete, count is stable)
     const int rest = Writer::Count(sh.writer);
     __syncthreads();
@@ -329,7 +346,8 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void TailLevelsKernel(
         slice.iteration = static_cast<VertexId>(iteration);
 
         const long long tiles = (static_cast<long long>(edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
-        ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, 0, tiles, sh);
+        unsigned accepted = 0;
+        ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, 0, tiles, sh, accepted);
         const int rest = Writer::Count(sh.writer);
         __syncthreads();
         Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void TailLevelsKernel(
 
 // Host-side launch.  Mirrors advance::LaunchKernel (advance/kernel.cuh:101-129) at the distilled level of
 // input/output frontier, graph, problem data, traversal type.
-template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true>
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true, bool COUNT_ONLY = false>
 hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
                         const typename ProblemData::DataSlice &slice, int max_grid_size, hipStream_t stream,
                         TYPE /*ADVANCE_TYPE: only V2V is on the BFS/SSSP path*/ = V2V)
@@ -359,10 +377,10 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
     if (args.in_len <= 0 || args.in_edges <= 0) return hipSuccess;
     const long long tiles = (static_cast<long long>(args.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
     if (max_grid_size <= 0)  // one resident wave of workgroups, each with a contiguous share of the tiles
-        max_grid_size = util::ResidentGrid(LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>, KernelPolicy::THREADS);
+        max_grid_size = util::ResidentGrid(LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, COUNT_ONLY>, KernelPolicy::THREADS);
     long long grid = tiles < max_grid_size ? tiles : max_grid_size;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES>), dim3(static_cast<unsigned>(grid)),
+    hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, COUNT_ONLY>), dim3(static_cast<unsigned>(grid)),
                        dim3(KernelPolicy::THREADS), 0, stream, args, slice);
     return util::GRError("advance::LoadBalancedKernel launch failed", __FILE__, __LINE__);
 }

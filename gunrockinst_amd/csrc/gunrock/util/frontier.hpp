@@ -39,6 +39,16 @@ __host__ __device__ __forceinline__ unsigned long long PackTail(unsigned count, 
 __host__ __device__ __forceinline__ unsigned TailCount(unsigned long long t) { return static_cast<unsigned>(t); }
 __host__ __device__ __forceinline__ unsigned TailEdges(unsigned long long t) { return static_cast<unsigned>(t >> 32); }
 
+// Host wait for the stream: spin on hipStreamQuery instead of hipStreamSynchronize.  The BSP loop waits dozens of times
+// per search for kernels that run 10-100 us; a blocking wait adds wake-up latency to each of them.
+inline hipError_t SpinSync(hipStream_t stream)
+{
+    hipError_t rc;
+    while ((rc = hipStreamQuery(stream)) == hipErrorNotReady) {
+    }
+    return rc;
+}
+
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
     static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
@@ -88,7 +98,7 @@ struct WorkProgress {
         GR_CHECK(hipMemcpyAsync(h_tail + (slot & 3), d_tail + (slot & 3), sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, stream),
                  "WorkProgress GetTail copy failed");
-        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetTail sync failed");
+        GR_CHECK(SpinSync(stream), "WorkProgress GetTail sync failed");
         count = TailCount(h_tail[slot & 3]);
         edges = TailEdges(h_tail[slot & 3]);
         return retval;
@@ -102,7 +112,7 @@ struct WorkProgress {
                  "WorkProgress GetAll copy failed");
         GR_CHECK(hipMemcpyAsync(h_sums, d_sums, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, stream),
                  "WorkProgress GetAll copy failed");
-        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetAll sync failed");
+        GR_CHECK(SpinSync(stream), "WorkProgress GetAll sync failed");
         return retval;
     }
     int *LevelsDone() { return reinterpret_cast<int *>(d_tail + 6); }
@@ -119,7 +129,7 @@ struct WorkProgress {
         hipError_t retval = hipSuccess;
         GR_CHECK(hipMemcpyAsync(h_tail + kAux, d_tail + kAux, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream),
                  "WorkProgress GetAux copy failed");
-        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress GetAux sync failed");
+        GR_CHECK(SpinSync(stream), "WorkProgress GetAux sync failed");
         count = TailCount(h_tail[kAux]);
         edges = TailEdges(h_tail[kAux]);
         return retval;

@@ -30,6 +30,7 @@ struct BfsRunner {
     virtual hipError_t Init(const Csr<int, int, int> &g) = 0;
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
+    virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
     virtual void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) = 0;
@@ -66,6 +67,13 @@ struct BfsRunnerT : BfsRunner {
         if (!problem.data_slices) return hipErrorNotInitialized;
         if (!d_iro || !d_ici) return problem.InverseIsSelf(alpha, beta);
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
+    }
+    void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) override
+    {
+        if (alpha > 0) problem.alpha = alpha;
+        if (beta > 0) problem.beta = beta;
+        if (lite_factor >= 0) problem.lite_factor = lite_factor;
+        if (tail_edge_limit >= 0) problem.tail_edge_limit = tail_edge_limit;
     }
     hipError_t Reset(int src, double queue_sizing) override
     {
@@ -190,6 +198,13 @@ int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const in
 {
     if (!p) return -1;
     return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, alpha, beta));
+}
+
+int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, int tail_edge_limit)
+{
+    if (!p) return -1;
+    p->runner->SetTuning(alpha, beta, lite_factor, tail_edge_limit);
+    return 0;
 }
 
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing)

@@ -74,6 +74,12 @@ int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, in
  * keep the defaults.  Takes effect with traversal_mode = 2 in grx_bfs_enact.  Call after init. */
 int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const int *d_inv_col_indices,
                               float alpha, float beta);
+/* Enactor tuning knobs (the reference exposes alpha/beta on its DOBFS command line, tests/dobfs/test_dobfs.cu:530-534):
+ * alpha, beta as above; lite_factor: a top-down level runs without queue output when frontier_edges*alpha*lite_factor
+ * exceeds the unexplored edges (0 disables); tail_edge_limit: levels with at most this many edges run inside the
+ * single-workgroup multi-level kernel (0 disables).  Non-positive alpha/beta and negative other values keep the current
+ * setting.  Results do not depend on any of these. */
+int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, int tail_edge_limit);
 /* BFSProblem::Reset(src, frontier_type, queue_sizing) (reference bfs_problem.cuh:272-360) */
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing);
 /* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579);

@@ -218,3 +218,23 @@ def test_dobfs_directed_graph_with_explicit_inverse():
             st = p.stats()
             p.close()
             _check(g, src, labels, preds, st)
+
+
+@pytest.mark.parametrize("lite_factor,tail_limit", [(1e9, 0), (1e9, 32768), (0.0, 0), (8.0, 100)])
+def test_enactor_schedules_do_not_change_results(lite_factor, tail_limit):
+    # force / forbid the count-only top-down level and the multi-level tail kernel: labels and parents must not move
+    for scale, ef in [(12, 8), (16, 8), (18, 16)]:
+        g = o.rmat_seeded(scale, ef << scale)
+        deg = np.diff(g.row_offsets)
+        srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist()
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph()
+            p.set_tuning(lite_factor=lite_factor, tail_edge_limit=tail_limit)
+            for src in srcs:
+                for mode in (0, 2):
+                    p.reset(int(src))
+                    p.enact(int(src), traversal_mode=mode)
+                    labels, preds = p.extract()
+                    _check(g, int(src), labels, preds, p.stats())
+            p.close()
