@@ -60,7 +60,7 @@ class BFSEnactor : public EnactorBase {
     typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> LBAdvancePolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
-    static constexpr int kTailEdgeLimit = 32768;
+    static constexpr int kTailEdgeLimit = 8192;  // default of BFSProblem::tail_edge_limit
     static constexpr int kTailMaxLevels = 4096;
 
     // traversal_mode: 0 = load-balanced top-down advance (reference default, bfs_enactor.cuh:581-697);
@@ -238,10 +238,10 @@ class BFSEnactor : public EnactorBase {
                 const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
                 long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
                 const long long cap = max_grid_size > 0 ? max_grid_size
-                    : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
+                    : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
                 if (grid > cap) grid = cap;
                 if (grid < 1) grid = 1;
-                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 4, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
+                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
                                    dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
                 if ((retval = util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__))) break;
                 cur_mask ^= 1;

@@ -117,7 +117,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     float alpha = 14.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges
     float beta = 24.0f;   // bottom-up -> top-down when frontier_vertices * beta < nodes
     float lite_factor = 8.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
-    int tail_edge_limit = 32768;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
+    int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 
     DataSlice **data_slices = nullptr;  // host copies (by-value kernel arguments), one per GPU
     DataSlice **d_data_slices = nullptr;  // kept for source compatibility; unused (no device-side struct)

@@ -239,29 +239,38 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                     pos = a.d_inv_row_offsets[v] + 2;
                     end = a.d_inv_row_offsets[v + 1];
                 }
-                // phase B: PROBE edges at a time, loads in flight together, up to SOLO_LIMIT edges per lane
-                for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
-                    if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
-                    VertexId nb[PROBE];
-                    bool fw[PROBE];
-                    if (active && p_found < 0 && pos + PROBE <= end && (PROBE % 4) == 0) {
+                // phase B: PROBE edges per round, up to SOLO_LIMIT edges per lane.  The round's in-neighbour ids were fetched
+                // during the PREVIOUS round (software prefetch), so their frontier probes and the next round's id loads are in
+                // flight together: one memory round trip per round instead of two (PMC: this loop is a pure latency chain).
+                VertexId cur[PROBE];
+                auto fetch = [&](VertexId (&dst)[PROBE], SizeT from, bool wanted) {
+                    if (wanted && from + PROBE <= end && (PROBE % 4) == 0) {
 #pragma unroll
                         for (int qd = 0; qd < PROBE / 4; ++qd) {  // 16-byte loads (rows are 4-byte aligned: gfx950 takes that)
-                            const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + pos + 4 * qd);
+                            const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + from + 4 * qd);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) nb[4 * qd + k] = q.v[k];
+                            for (int k = 0; k < 4; ++k) dst[4 * qd + k] = q.v[k];
                         }
                     } else {
 #pragma unroll
                         for (int k = 0; k < PROBE; ++k)
-                            nb[k] = (active && p_found < 0 && pos + k < end) ? a.d_inv_column_indices[pos + k] : static_cast<VertexId>(-1);
+                            dst[k] = (wanted && from + k < end) ? a.d_inv_column_indices[from + k] : static_cast<VertexId>(-1);
                     }
+                };
+                fetch(cur, pos, active && pos < end);
+                for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
+                    if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
+                    VertexId nxt[PROBE];
+                    fetch(nxt, pos + PROBE, active && p_found < 0 && pos + PROBE < end && done + PROBE < SOLO_LIMIT);
+                    bool fw[PROBE];
 #pragma unroll
-                    for (int k = 0; k < PROBE; ++k) fw[k] = (nb[k] >= 0) ? in_frontier(nb[k]) : false;
+                    for (int k = 0; k < PROBE; ++k) fw[k] = (active && p_found < 0 && cur[k] >= 0) ? in_frontier(cur[k]) : false;
 #pragma unroll
                     for (int k = 0; k < PROBE; ++k)
-                        if (p_found < 0 && fw[k]) p_found = nb[k];
+                        if (p_found < 0 && fw[k]) p_found = cur[k];
                     pos += PROBE;
+#pragma unroll
+                    for (int k = 0; k < PROBE; ++k) cur[k] = nxt[k];
                 }
                 // phase C: rows still unresolved are swept by the whole wave, 64 in-edges per step
                 unsigned long long todo = __ballot(active && p_found < 0 && pos < end);

@@ -152,6 +152,39 @@ __device__ __forceinline__ void ExpandTiles(
         // staged entries, because the degree prefix is increasing).
         int staged = 0;
         int owners = 0;
+        if (FRESH) {
+            // single-workgroup tail kernel: bandwidth is irrelevant, the chain of dependent round trips is everything, so all
+            // ITEMS rounds of the slice are fetched at once (a low-degree frontier otherwise costs one round trip per round)
+            SizeT rel[ITEMS], rw[ITEMS];
+            VertexId vx[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                const SizeT idx = cursor + r * THREADS + tid;
+                rel[r] = INT_MAX;
+                rw[r] = 0;
+                vx[r] = 0;
+                if (idx < a.in_len) {
+                    rel[r] = LoadQueue<true>(a.in.scan + idx) - slot0;
+                    rw[r] = LoadQueue<true>(a.in.row_start + idx);
+                    vx[r] = LoadQueue<true>(a.in.v + idx);
+                }
+            }
+            int wave_owners = 0;
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                sh.scan[r * THREADS + tid] = rel[r];
+                if (rel[r] < slots) {
+                    sh.row[r * THREADS + tid] = rw[r];
+                    sh.vertex[r * THREADS + tid] = vx[r];
+                }
+                wave_owners += __popcll(__ballot(rel[r] < slots));
+            }
+            if ((tid & (util::kWaveSize - 1)) == 0) sh.owner_count[0][tid / util::kWaveSize] = wave_owners;
+            __syncthreads();
+            staged = TILE;
+#pragma unroll
+            for (int w = 0; w < THREADS / util::kWaveSize; ++w) owners += sh.owner_count[0][w];
+        } else
         for (int base = 0, round = 0; base < TILE; base += THREADS, ++round) {
             const SizeT idx = cursor + base + tid;
             SizeT rel = INT_MAX;

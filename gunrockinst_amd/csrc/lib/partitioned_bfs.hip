@@ -327,10 +327,10 @@ struct Pbfs : app::EnactorBase {
         oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
         const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
         long long grid = (bu_steps + 3) / 4;
-        const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 4, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
+        const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
         if (grid > cap) grid = cap;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 4, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
+        hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
                            dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
         GR_CHECK(hipGetLastError(), "BottomUpKernel launch failed");
         if ((retval = work_progress.GetTail(1, frontier_len, frontier_edges, stream))) return retval;

@@ -1,0 +1,135 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the CPU oracle would need minutes here, and
+/root/reference is not on the GPU box).  torch is only the checker: it evaluates the defining properties of BFS depths,
+component labels and shortest distances edge by edge on the device.
+
+  BFS  (config 2: R-MAT scale-22; headline: scale-24)  label[src] = 0; labels of the two ends of an edge differ by at most
+       1 and are reached together; every reached vertex other than the source has a neighbour one level up; top-down and
+       direction-optimizing runs give identical labels; parents are neighbours one level up.
+  CC   (config 4: R-MAT scale-24)  ids are idempotent (id[id[v]] = id[v]), id[v] <= v, both ends of every edge share an id.
+  SSSP (config 3 stand-in: R-MAT scale-22, weights 1..64)  dist[src] = 0; no edge can improve its head
+       (dist[v] <= dist[u] + w); every reached vertex other than the source has a tight in-edge.
+The scale-22 BFS case is additionally compared bit for bit with the oracle (it finishes in ~0.3 s there).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gunrockinst_amd as ga
+from gunrockinst_amd import devgraph
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(scale):
+    ro, ci = devgraph.rmat_csr_device(scale, 8)
+    n, m = ro.shape[0] - 1, ci.shape[0]
+    src_of = torch.repeat_interleave(torch.arange(n, device="cuda", dtype=torch.int32), (ro[1:] - ro[:-1]).long())
+    return ro, ci, n, m, src_of
+
+
+def _bfs_properties(labels, preds, ro, ci, src_of, src, n):
+    assert int(labels[src]) == 0
+    lu, lv = labels[src_of.long()], labels[ci.long()]
+    reached_u, reached_v = lu >= 0, lv >= 0
+    assert bool((reached_u == reached_v).all())                       # undirected graph: components are reached whole
+    both = reached_u & reached_v
+    assert bool(((lu[both] - lv[both]).abs() <= 1).all())
+    # every reached vertex but the source has a neighbour exactly one level up: min over neighbours == label - 1
+    big = torch.full((n,), 1 << 30, dtype=torch.int32, device="cuda")
+    nmin = big.scatter_reduce(0, src_of.long(), torch.where(lv >= 0, lv, big[0]), reduce="amin", include_self=True)
+    reached = labels >= 0
+    reached[src] = False
+    assert bool((nmin[reached] == labels[reached] - 1).all())
+    if preds is not None:
+        assert int(preds[src]) == -1
+        p = preds[reached].long()
+        assert bool((p >= 0).all()) and bool((labels[p] == labels[reached] - 1).all())
+        # the parent is a neighbour: (v, pred[v]) must be an edge -> look the pair up in the sorted edge keys
+        keys = (src_of.long() << 32) | ci.long()
+        want = (torch.nonzero(reached).squeeze(1) << 32) | p
+        pos = torch.searchsorted(keys, want).clamp_(max=keys.shape[0] - 1)
+        assert bool((keys[pos] == want).all())
+        assert bool((preds[(labels < 0)] == -2).all())
+
+
+@pytest.mark.parametrize("scale", [22, 24])
+def test_bfs_fullsize_properties(scale):
+    ro, ci, n, m, src_of = _graph(scale)
+    src, _ = devgraph.largest_degree_source(ro)
+    sources = [src] + devgraph.seeded_sources(ro, 2)
+    p = ga.BfsProblem(mark_pred=True, idempotence=True).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    p.set_inverse_graph()
+    dl, dp = p.device_results()
+    labels, preds = devgraph.as_tensor(dl, n), devgraph.as_tensor(dp, n)
+    for s in sources:
+        p.reset(s)
+        p.enact(s, traversal_mode=0)
+        td = labels.clone()
+        _bfs_properties(td, preds.clone(), ro, ci, src_of, s, n)
+        p.reset(s)
+        p.enact(s, traversal_mode=2)
+        assert bool((labels == td).all())                             # schedule does not change the answer
+        _bfs_properties(labels, preds, ro, ci, src_of, s, n)
+    if scale == 22:                                                   # config 2: also bit-exact against the oracle
+        from oracle import gr_oracle as o
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        ref, _, _ = o.bfs(o.Csr(n, h_ro, h_ci), sources[0])
+        p.reset(sources[0])
+        p.enact(sources[0], traversal_mode=2)
+        got, _ = p.extract()
+        assert np.array_equal(got, ref)
+    p.close()
+
+
+def test_cc_scale24_properties():
+    ro, ci, n, m, src_of = _graph(24)
+    p = ga.CcProblem().init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    p.reset()
+    p.enact()
+    ids = devgraph.as_tensor(p.device_results(), n)
+    assert bool((ids[ids.long()] == ids).all())
+    assert bool((ids <= torch.arange(n, device="cuda", dtype=torch.int32)).all())
+    assert bool((ids[src_of.long()] == ids[ci.long()]).all())
+    # min-id representative: a root is the smallest member of its component
+    smallest = torch.full((n,), n, dtype=torch.int32, device="cuda").scatter_reduce(
+        0, ids.long(), torch.arange(n, device="cuda", dtype=torch.int32), reduce="amin", include_self=True)
+    roots = ids == torch.arange(n, device="cuda", dtype=torch.int32)
+    assert bool((smallest[roots] == torch.nonzero(roots).squeeze(1).int()).all())
+    _, count = p.extract()
+    assert count == int(roots.sum())
+    p.close()
+
+
+def test_sssp_scale22_properties():
+    ro, ci, n, m, src_of = _graph(22)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x6772)
+    w = torch.randint(1, 65, (m,), generator=gen, device="cuda", dtype=torch.int32)
+    src, _ = devgraph.largest_degree_source(ro)
+    delta = 32 * 32.0 / 15 * 16
+    for mark_pred in (False, True):
+        p = ga.SsspProblem(mark_pred).init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+        p.reset(src)
+        p.enact(src)
+        dist_h, preds_h = p.extract()
+        dist = torch.from_numpy(dist_h.astype(np.int64)).cuda()
+        inf = 0xFFFFFFFF
+        assert int(dist[src]) == 0
+        du, dv = dist[src_of.long()], dist[ci.long()]
+        ok = (du == inf) | (dv <= du + w.long())
+        assert bool(ok.all())                                         # no edge can still relax
+        cand = torch.where(du == inf, torch.full_like(du, 1 << 40), du + w.long())
+        best = torch.full((n,), 1 << 40, dtype=torch.int64, device="cuda").scatter_reduce(
+            0, ci.long(), cand, reduce="amin", include_self=True)     # graph is symmetric: in-edges = out-edges
+        reached = dist != inf
+        reached[src] = False
+        assert bool((best[reached] == dist[reached]).all())           # a tight in-edge exists
+        if mark_pred:
+            pr = torch.from_numpy(preds_h.astype(np.int64)).cuda()
+            keys = (src_of.long() << 32) | ci.long()
+            idx = torch.nonzero(reached).squeeze(1)
+            want = (pr[idx] << 32) | idx
+            pos = torch.searchsorted(keys, want).clamp_(max=keys.shape[0] - 1)
+            assert bool((keys[pos] == want).all())
+            assert bool((dist[pr[idx]] + w.long()[pos] == dist[idx]).all())
+        p.close()
