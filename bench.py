@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--primitive", choices=["bfs", "cc", "sssp"], default="bfs",
                     help="bfs = the headline metric (default); cc / sssp = BASELINE.json configs 4 / 3 on one GPU")
     ap.add_argument("--delta-factor", type=int, default=16)
+    ap.add_argument("--skip-topdown-leg", action="store_true",
+                    help="omit the secondary top-down-only figure (keeps rocprof summaries to the headline configuration)")
+    ap.add_argument("--alpha", type=float, default=0.0, help="direction switch tuning (0 = library default)")
+    ap.add_argument("--beta", type=float, default=0.0)
+    ap.add_argument("--lite-factor", type=float, default=-1.0)
     ap.add_argument("--traversal-mode", type=int, default=2,
                     help="0 = load-balanced top-down only, 2 = direction-optimizing (default)")
     return ap.parse_args()
@@ -99,6 +104,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     prob = ga.BfsProblem(mark_pred=False, idempotence=True, instrument=False, device=device_index)
     prob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
     prob.set_inverse_graph()          # the R-MAT graph is mirrored: its CSR is its own inverse
+    prob.set_tuning(args.alpha, args.beta, args.lite_factor)
     d_labels, _ = prob.device_results()
     labels_t = devgraph.as_tensor(d_labels, n)
 
@@ -132,7 +138,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
 
     # secondary figure: the same sources with the load-balanced top-down advance only (reference traversal_mode 0)
     td_ms, td_edges = 0.0, 0
-    for k in range(min(args.steps, 8)):
+    for k in range(0 if args.skip_topdown_leg else min(args.steps, 8)):
         td_ms += step(prob, k, 0)
         td_edges += per_src[sources[k % len(sources)]][1] if sources[k % len(sources)] in per_src else 0
     topdown_mteps = td_edges / (td_ms * 1e3) if td_ms > 0 and td_edges else None
@@ -141,7 +147,9 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob = ga.BfsProblem(False, True, instrument=True, device=device_index)
     iprob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
     iprob.set_inverse_graph()
-    names = {0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel", 2: "frontier conversion"}
+    iprob.set_tuning(args.alpha, args.beta, args.lite_factor)
+    names = {0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel", 2: "BitmapToQueue + TailLevelsKernel",
+             3: "advance::TailLevelsKernel", 4: "LoadBalancedKernel count-only + FreshToBitmapKernel"}
     by_kind = {}
     kernel_ms, launches, balg = 0.0, 0, 0.0
     for k in range(min(args.steps, len(sources))):

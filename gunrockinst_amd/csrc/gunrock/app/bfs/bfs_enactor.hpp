@@ -269,7 +269,7 @@ class BFSEnactor : public EnactorBase {
                     ds->lite = 0;
                     if (retval) break;
                     const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
-                    long long fgrid = (words64 + 3) / 4;
+                    long long fgrid = ((words64 + 7) / 8 + 3) / 4;  // 8 words per wave step, 4 waves per workgroup
                     if (fgrid > cu_count * 8) fgrid = cu_count * 8;
                     hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
                                        stream, ds->d_fresh, static_cast<long long>(problem->nodes),

@@ -55,6 +55,13 @@ class Comm:
     def _stage(self, t):
         return t.cpu() if (self.host_staged and t.is_cuda) else t
 
+    def _fence(self):
+        """RCCL work is enqueued on torch's stream; the engine's kernels run on their own HIP stream.  Make the collective's
+        output visible to them: wait on the host until torch's current stream has drained.  (The engine side always returns
+        to Python with its stream synchronised, so the other direction needs nothing.)"""
+        if not self.host_staged:
+            torch.cuda.current_stream().synchronize()
+
     def all_reduce_sum(self, values):
         t = torch.tensor(values, dtype=torch.int64)
         if not self.host_staged:
@@ -83,6 +90,7 @@ class Comm:
         s = self._stage(send)
         r = torch.empty(int(sum(recv_counts)), dtype=torch.int32, device=s.device)
         dist.all_to_all_single(r, s, list(recv_counts), list(send_counts), group=self.group)
+        self._fence()
         return r.to(dev) if r.device != dev else r
 
     def all_gather(self, t):
@@ -90,6 +98,7 @@ class Comm:
         s = self._stage(t)
         out = torch.empty(self.world * s.numel(), dtype=s.dtype, device=s.device)
         dist.all_gather_into_tensor(out, s, group=self.group)
+        self._fence()
         return out.to(dev) if out.device != dev else out
 
     def barrier(self):
@@ -104,7 +113,7 @@ class PartitionedBfs:
     filter_received(recv_tensor)->(len, edges); queue_to_bitmap(); frontier_bitmap()->int32 tensor;
     bottom_up(gathered_tensor, words_per_rank)->(len, edges); bitmap_to_queue()->(len, edges)."""
 
-    def __init__(self, engine, comm, n_global, m_global, alpha=14.0, beta=24.0):
+    def __init__(self, engine, comm, n_global, m_global, alpha=10.0, beta=24.0):
         self.engine, self.comm = engine, comm
         self.n_global, self.m_global = int(n_global), int(m_global)
         self.alpha, self.beta = float(alpha), float(beta)
