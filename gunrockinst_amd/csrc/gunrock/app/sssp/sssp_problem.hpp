@@ -34,7 +34,7 @@ __global__ void InitDistPredKernel(unsigned long long *d_dist_pred, long long no
         d_dist_pred[i] = (0xFFFFFFFFull << 32) | static_cast<unsigned>(i);  // unreached, pred = own id (iota init)
 }
 
-__global__ inline void SplitDistPredKernel(const unsigned long long *d_dist_pred, long long nodes, unsigned *d_labels,
+static __global__ void SplitDistPredKernel(const unsigned long long *d_dist_pred, long long nodes, unsigned *d_labels,
                                            int *d_preds)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;

@@ -32,7 +32,6 @@ struct PbfsProblem {
     typedef int SizeT;
     typedef int Value;
     static constexpr bool MARK_PREDECESSORS = false;
-    static constexpr bool ENABLE_IDEMPOTENCE = true;
     struct DataSlice {
         int *d_labels;              // local
         int *d_preds;               // unused (MARK_PREDECESSORS = false)

@@ -107,3 +107,22 @@ def seeded_sources(row_offsets, count, seed=0x6772):
 def to_host_csr(row_offsets, col_indices):
     return (row_offsets.cpu().numpy().astype(np.int32, copy=False),
             col_indices.cpu().numpy().astype(np.int32, copy=False))
+
+
+def grid_csr_device(side, shortcut_fraction=0.01, seed=0x6772, device="cuda"):
+    """Road-like stand-in of SURVEY 8(d): side x side 4-neighbour grid plus `shortcut_fraction` * n random shortcuts,
+    undirected.  Average degree ~4, so the reference driver would pick traversal_mode 1 (test_bfs.cu:563-566)."""
+    n = side * side
+    v = torch.arange(n, device=device, dtype=torch.int64)
+    x, y = v % side, v // side
+    right = v[x < side - 1]
+    down = v[y < side - 1]
+    rows = torch.cat([right, down])
+    cols = torch.cat([right + 1, down + side])
+    k = int(n * shortcut_fraction)
+    if k > 0:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        rows = torch.cat([rows, torch.randint(0, n, (k,), generator=gen, device=device)])
+        cols = torch.cat([cols, torch.randint(0, n, (k,), generator=gen, device=device)])
+    return csr_from_tuples_device(n, rows.int(), cols.int(), undirected=True)

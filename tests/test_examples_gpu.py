@@ -20,3 +20,42 @@ def test_c_program_known_answer(name, regex):
     out = subprocess.run([os.path.join(ROOT, "examples", name)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert re.search(regex, out.stdout), out.stdout
+
+
+def _run(cmd, timeout=300):
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+
+
+def test_simple_example_prints_test_passed():
+    # reference ctest "SimpleExample" (CMakeLists.txt:239-241): CC + BFS self-check on bips98_606.mtx ends with TEST PASSED
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "simple_example", "-s"])
+    out = _run([os.path.join(ROOT, "examples", "simple_example"), "market", os.path.join(ROOT, "tests", "golden", "bips98_606.mtx")])
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "TEST PASSED" in out.stdout and "Label Validity: \nCORRECT" in out.stdout
+    assert "CPU components: 542, GPU components: 542" in out.stdout
+    assert "7135 nodes, 30380 edges" in out.stdout
+
+
+@pytest.mark.parametrize("flags", [
+    ["--undirected", "--src=largestdegree", "--quick=0"],
+    ["--undirected", "--src=0", "--quick=0", "--mark-pred", "--idempotence=0", "--traversal-mode=0"],
+    ["--undirected", "--src=566", "--quick=0", "--mark-pred", "--traversal-mode=2", "--iteration-num=3", "--instrumented"],
+    ["--src=randomize", "--quick=0", "--idempotence=0"],
+])
+def test_test_bfs_cli_flags(flags):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "test_bfs_cli", "-s"])
+    out = _run([os.path.join(ROOT, "examples", "test_bfs_cli"), "market", os.path.join(ROOT, "tests", "golden", "bips98_606.mtx")] + flags)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Label Validity: \nCORRECT" in out.stdout and "MiEdges/s" in out.stdout
+    if "--mark-pred" in flags:
+        assert "Predecessor Validity: CORRECT" in out.stdout
+    if "--src=largestdegree" in flags:
+        assert "Using highest degree (111) vertex: 566" in out.stdout
+
+
+def test_test_bfs_cli_rmat_matches_reference_graph_size():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "test_bfs_cli", "-s"])
+    out = _run([os.path.join(ROOT, "examples", "test_bfs_cli"), "rmat", "--quick=0", "--src=largestdegree"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Graph: 1024 nodes, 997 edges" in out.stdout              # libc R-MAT golden
+    assert "Label Validity: \nCORRECT" in out.stdout
