@@ -60,26 +60,37 @@ class BFSEnactor : public EnactorBase {
     typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> LBAdvancePolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
+    // Persistent mid-size levels: 512-thread workgroups (one edge slot per thread: the level is latency-bound, so spread it
+    // wide), at most one per CU, grid barrier between levels.
+    typedef oprtr::advance::KernelPolicy<512, 1, 1, oprtr::advance::LB> PersistentPolicy;
     static constexpr int kTailEdgeLimit = 8192;  // default of BFSProblem::tail_edge_limit
     static constexpr int kTailMaxLevels = 4096;
 
     // traversal_mode: 0 = load-balanced top-down advance (reference default, bfs_enactor.cuh:581-697);
-    //                 1 = reserved for the TWC advance (falls back to LB);
+    //                 1 = the reference's TWC choice for low-degree graphs: LB advance + persistent mid-size levels;
     //                 2 = direction-optimizing (reference app/dobfs): needs BFSProblem::SetInverseGraph.
     template <typename BFSProblem>
     hipError_t Enact(util::DeviceContext & /*context*/, BFSProblem *problem, typename BFSProblem::VertexId src,
                      int max_grid_size = 0, int traversal_mode = 0)
     {
+        // The reference's driver picks mode 1 (TWC) for graphs of average degree <= 8 (tests/bfs/test_bfs.cu:563-566): long
+        // runs of small levels.  Here that case is served by the persistent levels kernel, enabled by mode 1 or by the
+        // same average-degree rule; on scale-free graphs a mid-size level is a one-level transition and a plain launch wins.
+        const bool low_degree = static_cast<long long>(problem->edges) <= 8ll * problem->nodes;
         return EnactBFS<LBAdvancePolicy, BFSProblem>(problem, src, max_grid_size,
-                                                     traversal_mode == 2 && problem->direction_optimizing);
+                                                     traversal_mode == 2 && problem->direction_optimizing,
+                                                     traversal_mode == 1 || low_degree);
     }
 
    protected:
     // Launch the multi-level tail kernel on queue[selector] (its length lives in ring slot iteration & 3), wait, and
     // bring the host's view (iteration, selector, frontier size, statistics) up to date.
+    // `persistent`: use the multi-workgroup kernel with a grid barrier (mid-size frontiers) instead of the single workgroup;
+    // `switch_factor` > 0 makes it hand back as soon as a level's edges * factor exceed the unexplored edges (the host then
+    // applies the direction-optimizing rules).
     template <typename BFSProblem, typename BfsFunctor>
     hipError_t RunTail(BFSProblem *problem, long long &iteration, int &selector, unsigned &queue_length, unsigned &queue_edges,
-                       long long &unexplored_edges, hipStream_t stream)
+                       long long &unexplored_edges, hipStream_t stream, bool persistent = false, double switch_factor = 0.0)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
@@ -99,10 +110,34 @@ class BFSEnactor : public EnactorBase {
         t.d_row_offsets = gs->d_row_offsets;
         t.d_column_indices = gs->d_column_indices;
         t.d_overflow = work_progress.d_overflow;
-        if ((retval = oprtr::advance::LaunchTailLevels<TailPolicy, BFSProblem, BfsFunctor>(t, *problem->data_slices[0], stream)))
+        if (persistent) {
+            oprtr::advance::PersistentArgs<VertexId, SizeT> p;
+            p.t = t;
+            // Grid barrier cost grows with the number of workgroups (2048^2 grid graph, ~16 K edges per level: 16 us per
+            // level with 32 workgroups, 23 us with 256), so size the grid to the entry frontier (one tile per workgroup,
+            // at least 16) and hand back to the host when the frontier outgrows it 8-fold; the host relaunches larger.
+            long long grid = (static_cast<long long>(queue_edges) + PersistentPolicy::TILE - 1) / PersistentPolicy::TILE;
+            if (grid < 16) grid = 16;
+            if (grid > cu_count) grid = cu_count;
+            long long limit = grid * PersistentPolicy::TILE * 8;
+            if (grid == cu_count || limit > problem->persistent_edge_limit) limit = problem->persistent_edge_limit;
+            p.t.edge_limit = static_cast<SizeT>(limit);
+            p.barrier.d_counter = work_progress.BarrierCounter();
+            p.barrier.d_timeout = work_progress.BarrierTimeout();
+            p.min_edges = problem->tail_edge_limit / 4;  // hysteresis: only really small levels go back to one workgroup
+            p.unexplored_edges = unexplored_edges;
+            p.switch_factor = switch_factor;
+            if ((retval = oprtr::advance::LaunchPersistentLevels<PersistentPolicy, BFSProblem, BfsFunctor>(
+                     p, *problem->data_slices[0], cu_count, static_cast<int>(grid), stream)))
+                return retval;
+        } else if ((retval = oprtr::advance::LaunchTailLevels<TailPolicy, BFSProblem, BfsFunctor>(t, *problem->data_slices[0],
+                                                                                                   stream)))
             return retval;
         if (INSTRUMENT && (retval = InstrumentEnd(stream))) return retval;
         if ((retval = work_progress.GetAll(stream))) return retval;
+        if (persistent && work_progress.HostBarrierTimedOut())
+            return util::GRError(hipErrorLaunchTimeOut, "BFSEnactor persistent levels kernel: grid barrier timed out", __FILE__,
+                                 __LINE__);
         const int done = work_progress.HostLevelsDone();
         iteration += done;
         selector ^= (done & 1);
@@ -116,7 +151,8 @@ class BFSEnactor : public EnactorBase {
     }
 
     template <typename AdvancePolicy, typename BFSProblem>
-    hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size, bool dobfs)
+    hipError_t EnactBFS(BFSProblem *problem, typename BFSProblem::VertexId src, int max_grid_size, bool dobfs,
+                        bool persistent_levels)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
@@ -210,6 +246,20 @@ class BFSEnactor : public EnactorBase {
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 3);
                 if (iteration != before) continue;
                 if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;  // no level ran: fall through to the grid kernel
+            } else if (persistent_levels && !bottom_up &&
+                       queue_edges <= static_cast<unsigned>(problem->persistent_edge_limit) &&
+                       !(dobfs && static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor >
+                                      static_cast<double>(unexplored_edges))) {
+                // mid-size top-down frontier: resident workgroups run consecutive levels with a grid barrier in between
+                const long long before = iteration;
+                snapshot_valid = false;
+                if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
+                                                              unexplored_edges, stream, true,
+                                                              dobfs ? problem->alpha * problem->lite_factor : 0.0)))
+                    break;
+                if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 5);
+                if (iteration != before) continue;
+                if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
             }
             enactor_stats.total_queued += queue_length;
             enactor_stats.total_edges_queued += queue_edges;

@@ -117,6 +117,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     float alpha = 10.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges (measured optimum 8..14 on R-MAT)
     float beta = 24.0f;   // bottom-up -> top-down when frontier_vertices * beta < nodes
     float lite_factor = 12.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
+    int persistent_edge_limit = 1 << 20;  // ... and up to this many inside the persistent multi-workgroup kernel (0 = off)
     int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 
     DataSlice **data_slices = nullptr;  // host copies (by-value kernel arguments), one per GPU

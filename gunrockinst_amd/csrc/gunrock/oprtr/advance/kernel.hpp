@@ -20,6 +20,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <climits>
 #include <type_traits>
 
@@ -416,6 +417,145 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
     hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, COUNT_ONLY>), dim3(static_cast<unsigned>(grid)),
                        dim3(KernelPolicy::THREADS), 0, stream, args, slice);
     return util::GRError("advance::LoadBalancedKernel launch failed", __FILE__, __LINE__);
+}
+
+// ---- persistent multi-workgroup levels: the same idea for MID-SIZE frontiers (8 K .. ~1 M edge slots) ----
+// A 2048 x 2048 grid graph runs 2049 levels of ~16 K edges: as separate launches each costs ~20 us of kernel plus ~40 us of
+// host round trip (62 ms per search).  Here `gridDim.x` resident workgroups (one per CU at most) stay in the kernel, split
+// every level's edge slots evenly, and meet at a grid barrier between levels.  The barrier is the counter form of the
+// programming guide's inter-workgroup recipe: every workgroup drains its stores, one lane issues an agent-scope release,
+// adds to a monotonic counter, polls it with relaxed agent loads + s_sleep, then issues one agent-scope acquire.  Spins are
+// bounded: a workgroup that waits too long raises `*d_timeout` and everybody leaves (the enactor reports the failure).
+// Residency is what makes the barrier safe: the launch code caps the grid at the occupancy of this kernel and at the CU
+// count, and nothing else is running on the stream's device at that time.
+struct GridBarrierState {
+    unsigned *d_counter;   // zeroed by the host before every launch
+    int *d_timeout;        // = d_counter + 1; zeroed together with it
+};
+
+__device__ __forceinline__ bool GridBarrier(const GridBarrierState &b, unsigned &epoch)
+{
+    __shared__ int s_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        epoch += 1;
+        const unsigned target = epoch * gridDim.x;
+        __hip_atomic_fetch_add(b.d_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(b.d_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 4000000u || __hip_atomic_load(b.d_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(b.d_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_load(b.d_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+template <typename VertexId, typename SizeT>
+struct PersistentArgs {
+    TailArgs<VertexId, SizeT> t;
+    GridBarrierState barrier;
+    SizeT min_edges;           // leave when a level has FEWER edge slots than this (the single-workgroup kernel is cheaper)
+    long long unexplored_edges;  // direction-optimizing: leave when edges * switch_factor > unexplored (0 factor = never)
+    double switch_factor;
+};
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
+    PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> p, typename ProblemData::DataSlice slice)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT> Shared;
+    typedef typename Shared::Writer Writer;
+    __shared__ Shared sh;
+    const TailArgs<VertexId, SizeT> &t = p.t;
+
+    Writer::Init(sh.writer);
+    int selector = t.selector;
+    long long iteration = t.first_iteration;
+    long long unexplored = p.unexplored_edges;
+    int done = 0;
+    unsigned epoch = 0;
+    unsigned long long sum_len = 0, sum_edges = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            sh.level_tail = __hip_atomic_load(t.d_tail + (iteration & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0)
+                __hip_atomic_store(t.d_tail + ((iteration + 2) & 3), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned long long tail = sh.level_tail;
+        const SizeT len = static_cast<SizeT>(util::TailCount(tail));
+        const SizeT edges = static_cast<SizeT>(util::TailEdges(tail));
+        // every workgroup evaluates the same values => the same decision
+        if (len == 0 || edges > t.edge_limit || edges < p.min_edges || done >= t.max_levels) break;
+        if (p.switch_factor > 0 && static_cast<double>(edges) * p.switch_factor > static_cast<double>(unexplored)) break;
+
+        AdvanceArgs<VertexId, SizeT> a;
+        a.in = t.queue[selector];
+        a.out = t.queue[selector ^ 1];
+        a.in_len = len;
+        a.in_edges = edges;
+        a.d_row_offsets = t.d_row_offsets;
+        a.d_column_indices = t.d_column_indices;
+        a.d_tail_out = t.d_tail + ((iteration + 1) & 3);
+        a.d_tail_clear = nullptr;
+        a.d_overflow = t.d_overflow;
+        slice.iteration = static_cast<VertexId>(iteration);
+
+        const long long tiles = (static_cast<long long>(edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+        const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
+        const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
+        const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
+        if (tile_begin < tile_end) {  // workgroup-uniform
+            unsigned accepted = 0;
+            ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, tile_begin, tile_end, sh, accepted);
+            const int rest = Writer::Count(sh.writer);
+            __syncthreads();
+            Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+        }
+        if (!GridBarrier(p.barrier, epoch)) break;  // (timeout: every workgroup sees the flag and leaves)
+        selector ^= 1;
+        ++iteration;
+        ++done;
+        sum_len += len;
+        sum_edges += edges;
+        unexplored -= edges;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *t.d_levels_done = done;
+        t.d_level_sums[0] = sum_len;
+        t.d_level_sums[1] = sum_edges;
+    }
+}
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+hipError_t LaunchPersistentLevels(const PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
+                                  const typename ProblemData::DataSlice &slice, int cu_count, int grid_hint, hipStream_t stream)
+{
+    hipError_t retval = hipSuccess;
+    int grid = util::ResidentGrid(PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>, KernelPolicy::THREADS);
+    if (grid > cu_count) grid = cu_count;  // one workgroup per CU: every one of them is resident
+    if (grid_hint > 0 && grid_hint < grid) grid = grid_hint;  // small levels: fewer workgroups = cheaper barrier
+    if (grid < 1) grid = 1;
+    // contract: the two words are adjacent (WorkProgress slot 7), so one 8-byte memset re-arms both
+    GR_CHECK(hipMemsetAsync(args.barrier.d_counter, 0, 2 * sizeof(unsigned), stream), "PersistentLevels clear barrier failed");
+    hipLaunchKernelGGL((PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(grid), dim3(KernelPolicy::THREADS), 0,
+                       stream, args, slice);
+    return util::GRError("advance::PersistentLevelsKernel launch failed", __FILE__, __LINE__);
 }
 
 template <typename KernelPolicy, typename ProblemData, typename Functor>

@@ -52,7 +52,7 @@ inline hipError_t SpinSync(hipStream_t stream)
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
     static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
-                                           // 7: spare; tail-kernel sums live in d_sums[2]
+                                           // 7: grid barrier (counter | timeout); tail-kernel sums live in d_sums[2]
     static constexpr int kAux = 4;
     unsigned long long *d_tail = nullptr;  // [kSlots] packed (edges<<32 | vertices)
     int *d_overflow = nullptr;             // set when a writer ran out of queue capacity
@@ -115,6 +115,10 @@ struct WorkProgress {
         GR_CHECK(SpinSync(stream), "WorkProgress GetAll sync failed");
         return retval;
     }
+    // slot 7: grid-barrier counter (low word) and its timeout flag (high word) of the persistent levels kernel
+    unsigned *BarrierCounter() { return reinterpret_cast<unsigned *>(d_tail + 7); }
+    int *BarrierTimeout() { return reinterpret_cast<int *>(d_tail + 7) + 1; }
+    bool HostBarrierTimedOut() const { return (h_tail[7] >> 32) != 0; }
     int *LevelsDone() { return reinterpret_cast<int *>(d_tail + 6); }
     int HostLevelsDone() const { return *reinterpret_cast<const int *>(h_tail + 6); }
 

@@ -31,6 +31,7 @@ struct BfsRunner {
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
+    virtual void SetPersistentLimit(int limit) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
     virtual void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) = 0;
@@ -68,6 +69,7 @@ struct BfsRunnerT : BfsRunner {
         if (!d_iro || !d_ici) return problem.InverseIsSelf(alpha, beta);
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
     }
+    void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
     void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) override
     {
         if (alpha > 0) problem.alpha = alpha;
@@ -198,6 +200,13 @@ int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const in
 {
     if (!p) return -1;
     return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, alpha, beta));
+}
+
+int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit)
+{
+    if (!p || !p->runner || edge_limit < 0) return 1;
+    p->runner->SetPersistentLimit(edge_limit);
+    return 0;
 }
 
 int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, int tail_edge_limit)

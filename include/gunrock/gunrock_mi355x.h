@@ -80,10 +80,15 @@ int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const in
  * single-workgroup multi-level kernel (0 disables).  Non-positive alpha/beta and negative other values keep the current
  * setting.  Results do not depend on any of these. */
 int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, int tail_edge_limit);
+/* Top-down levels with more than tail_edge_limit and at most `edge_limit` edges run inside the persistent multi-workgroup
+ * kernel (one resident workgroup per CU, grid barrier between levels; 0 disables).  This is what the reference's
+ * traversal_mode 1 (TWC advance for low-degree, high-diameter graphs, tests/bfs/test_bfs.cu:563-566) is for. */
+int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit);
 /* BFSProblem::Reset(src, frontier_type, queue_sizing) (reference bfs_problem.cuh:272-360) */
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing);
 /* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579);
- * traversal_mode 0 = load-balanced top-down, 1 = reserved (TWC), 2 = direction-optimizing;
+ * traversal_mode 0 = load-balanced top-down, 1 = low-degree/high-diameter choice of the reference driver (its TWC
+ * advance; here LB advance + persistent mid-size levels kernel), 2 = direction-optimizing;
  * bracketed by HIP events on the problem's stream like the reference's GpuTimer (test_bfs.cu:408-438) */
 int grx_bfs_enact(grx_bfs *p, int src, int max_grid_size, int traversal_mode, float *elapsed_ms);
 /* BFSEnactor::GetStatistics (reference bfs_enactor.cuh:173-186) plus, when instrumented, operator-kernel

@@ -238,3 +238,31 @@ def test_enactor_schedules_do_not_change_results(lite_factor, tail_limit):
                     labels, preds = p.extract()
                     _check(g, int(src), labels, preds, p.stats())
             p.close()
+
+
+@pytest.mark.parametrize("persistent_limit,tail_limit", [(1 << 20, 8192), (1 << 20, 0), (1 << 14, 256), (0, 8192)])
+def test_persistent_levels_kernel_parity(persistent_limit, tail_limit):
+    # mid-size levels inside the persistent multi-workgroup kernel (grid barrier between levels) versus launch-per-level:
+    # road-like grids (long diameter, ~4 neighbours: the reference's traversal_mode 1 case, test_bfs.cu:563-566) and R-MAT
+    import torch
+    from gunrockinst_amd import devgraph
+    graphs = []
+    for side, frac in [(256, 0.0), (300, 0.01)]:
+        ro, ci = devgraph.grid_csr_device(side, frac)
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        graphs.append((o.Csr(side * side, h_ro, h_ci), [0, side * side // 2 + side // 2]))
+    g = o.rmat_seeded(16, 8 << 16)
+    graphs.append((g, [o.highest_degree_node(g)[0], int(np.nonzero(np.diff(g.row_offsets) == 1)[0][0])]))
+    for g, srcs in graphs:
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph()
+            p.set_tuning(tail_edge_limit=tail_limit)
+            p.set_persistent_limit(persistent_limit)
+            for src in srcs:
+                for mode in (0, 1, 2):
+                    p.reset(int(src))
+                    p.enact(int(src), traversal_mode=mode)
+                    labels, preds = p.extract()
+                    _check(g, int(src), labels, preds, p.stats())
+            p.close()
