@@ -285,6 +285,8 @@ class BFSEnactor : public EnactorBase {
                 bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
                 bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
+                bargs.d_wide = work_progress.d_wide;
+                if ((retval = work_progress.ClearWide(stream))) break;
                 const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
                 long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
                 const long long cap = max_grid_size > 0 ? max_grid_size
@@ -313,26 +315,28 @@ class BFSEnactor : public EnactorBase {
                                   static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges);
                 if (lite) {
                     ds->lite = 1;
-                    args.d_tail_out = work_progress.AuxTail();  // the advance's own count includes duplicates: discarded
+                    args.d_tail_out = nullptr;  // the advance's own count includes duplicates: not wanted
                     retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor, true, true>(
                         args, *ds, max_grid_size, stream, oprtr::advance::V2V);
                     ds->lite = 0;
                     if (retval) break;
                     const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
-                    long long fgrid = ((words64 + 7) / 8 + 3) / 4;  // 8 words per wave step, 4 waves per workgroup
-                    if (fgrid > cu_count * 8) fgrid = cu_count * 8;
+                    long long fgrid = ((words64 + 15) / 16 + 3) / 4;  // 16 words per wave step, 4 waves per workgroup
+                    if (fgrid > cu_count * 4) fgrid = cu_count * 4;
+                    if ((retval = work_progress.ClearWide(stream))) break;
                     hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
                                        stream, ds->d_fresh, static_cast<long long>(problem->nodes),
                                        reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
                                        reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
                                        reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), ds->d_labels,
-                                       static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3));
+                                       static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3),
+                                       work_progress.d_wide);
                     if ((retval = util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__))) break;
                     cur_mask = 0;
                     force_bottom_up = true;
                     if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                     ++iteration;
-                    if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+                    if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
                     if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 4);
                     continue;  // (selector unchanged: no queue was written)
                 }
@@ -344,7 +348,10 @@ class BFSEnactor : public EnactorBase {
             if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
 
             ++iteration;
-            if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+            if (bottom_up) {
+                if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+            } else if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream)))
+                break;
             if (INSTRUMENT) InstrumentCollect(in_len, in_edges, bottom_up ? 1 : 0);
             if (DEBUG) std::printf("iteration %lld (%s): queue length %u, edges %u\n", iteration,
                                    bottom_up ? "bottom-up" : "top-down", queue_length, queue_edges);

@@ -168,7 +168,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipMalloc(&ds->d_never_mask, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
                      "BFSProblem hipMalloc d_never_mask failed");
         if (!ds->d_fresh) {
-            const size_t bytes = (static_cast<size_t>(this->nodes) + 255) / 256 * 256 + 256;
+            const size_t bytes = (static_cast<size_t>(this->nodes) + 1023) / 1024 * 1024 + 1024;  // FreshToBitmapKernel reads 1 KiB steps
             GR_CHECK(hipMalloc(&ds->d_fresh, bytes), "BFSProblem hipMalloc d_fresh failed");
             GR_CHECK(hipMemset(ds->d_fresh, 0, bytes), "BFSProblem hipMemset d_fresh failed");  // levels leave it zero again
         }

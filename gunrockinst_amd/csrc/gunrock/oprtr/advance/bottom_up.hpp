@@ -59,46 +59,58 @@ static __global__ void BitmapDiffKernel(const unsigned long long *d_now, const u
 template <typename VertexId>
 __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, unsigned long long *d_visited,
                                     const unsigned long long *d_visited_before, unsigned long long *d_frontier_out,
-                                    VertexId *d_labels, VertexId label, unsigned long long *d_tail_out)
+                                    VertexId *d_labels, VertexId label, unsigned long long *d_tail_out,
+                                    unsigned long long *d_wide)
 {
-    constexpr int STEP_WORDS = 8;  // 512 vertices per wave step: 8 independent byte loads per lane in flight (the one-word
-                                   // version was a chain of dependent round trips: 127 us for a 16 MiB map)
+    // One wave step = 1024 vertices: every lane loads its 16 flag bytes with ONE 16-byte load (the byte-per-lane version
+    // issued 16x the load instructions and ran at 107 us for a 16 MiB map), squeezes them into 16 bits, and four
+    // neighbouring lanes assemble one 64-bit bitmap word.  d_fresh is padded to a multiple of 1024 bytes (bfs_problem.hpp).
     const unsigned lane = util::LaneId();
     const long long words = (nodes + 63) / 64;
-    const long long steps = (words + STEP_WORDS - 1) / STEP_WORDS;
+    const long long steps = (words + 15) / 16;
     const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize;
     const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
+    const unsigned quad = lane & 3u;
     unsigned count = 0;
     for (long long step = wave0; step < steps; step += nwaves) {
-        const long long my_word = step * STEP_WORDS + lane;
-        const bool owns_word = lane < STEP_WORDS && my_word < words;
-        // "seen" is the bitmap as it was BEFORE the level (d_visited may carry best-effort bits of this level)
-        unsigned long long my_seen = ~0ull;
-        if (owns_word) my_seen = d_visited_before[my_word];
-        unsigned char flag[STEP_WORDS];
-#pragma unroll
-        for (int j = 0; j < STEP_WORDS; ++j) {
-            const long long v = (step * STEP_WORDS + j) * 64 + lane;
-            flag[j] = (v < nodes) ? d_fresh[v] : static_cast<unsigned char>(0);
+        const long long my_word = step * 16 + (lane >> 2);
+        const bool in_range = my_word < words;
+        uint4 *my_flags = reinterpret_cast<uint4 *>(d_fresh) + (step * 64 + lane);
+        const uint4 f = *my_flags;
+        // "seen" is the bitmap as it was BEFORE the level (the four lanes of a quad read the same word: one request)
+        const unsigned long long seen = in_range ? d_visited_before[my_word] : ~0ull;
+        // bytes are 0 or 1: (w * 0x01020408) >> 24 gathers the four low bits of a dword's bytes
+        const unsigned m16 = ((f.x * 0x01020408u) >> 24 & 0xFu) | ((f.y * 0x01020408u) >> 24 & 0xFu) << 4 |
+                             ((f.z * 0x01020408u) >> 24 & 0xFu) << 8 | ((f.w * 0x01020408u) >> 24 & 0xFu) << 12;
+        if (m16) *my_flags = make_uint4(0, 0, 0, 0);
+        unsigned long long word = static_cast<unsigned long long>(m16) << (16 * quad);
+        word |= __shfl_xor(word, 1, util::kWaveSize);
+        word |= __shfl_xor(word, 2, util::kWaveSize);
+        const unsigned long long mask = word & ~seen;
+        unsigned mine = static_cast<unsigned>(mask >> (16 * quad)) & 0xFFFFu;
+        const long long v0 = (step * 64 + lane) * 16;
+        while (mine) {
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1;
+            d_labels[v0 + b] = label;
         }
-        unsigned long long my_mask = 0;
-#pragma unroll
-        for (int j = 0; j < STEP_WORDS; ++j) {
-            const long long v = (step * STEP_WORDS + j) * 64 + lane;
-            const unsigned long long seen = __shfl(my_seen, j, util::kWaveSize);
-            const unsigned long long mask = __ballot(flag[j] != 0) & ~seen;
-            if (flag[j] != 0) d_fresh[v] = 0;
-            if ((mask >> lane) & 1ull) d_labels[v] = label;
-            if (static_cast<int>(lane) == j) my_mask = mask;
-        }
-        if (owns_word) {
-            d_frontier_out[my_word] = my_mask;
-            d_visited[my_word] = my_seen | my_mask;  // authoritative
-            count += static_cast<unsigned>(__popcll(my_mask));
+        if (quad == 0 && in_range) {
+            d_frontier_out[my_word] = mask;
+            d_visited[my_word] = seen | mask;  // authoritative
+            count += static_cast<unsigned>(__popcll(mask));
         }
     }
+    // workgroup total -> one atomic on this workgroup's line of the wide tail (or on d_tail_out when there is none)
+    __shared__ unsigned long long s_wave_total[16];
     unsigned long long total = util::WaveSum(static_cast<unsigned long long>(count));
-    if (lane == 0 && total) atomicAdd(d_tail_out, total);
+    if (lane == 0) s_wave_total[threadIdx.x / util::kWaveSize] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (unsigned w = 0; w < blockDim.x / util::kWaveSize; ++w) sum += s_wave_total[w];
+        unsigned long long *slot = util::WideTailSlot(d_wide);
+        if (sum) atomicAdd(slot ? slot : d_tail_out, sum);
+    }
 }
 
 // Frontier membership tests for the bottom-up sweep.
@@ -135,6 +147,7 @@ struct BottomUpArgs {
     unsigned long long *d_visited;          // visited bitmap, owner-updated
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
+    unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
 };
 
 // 64-vertex bitmap words one wave takes per step of the bottom-up sweep (launch code sizes the grid from it)
@@ -360,7 +373,8 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
         unsigned long long sum = 0;
 #pragma unroll
         for (int i = 0; i < WAVES; ++i) sum += s_total[i];
-        if (sum) atomicAdd(a.d_tail_out, sum);
+        unsigned long long *slot = util::WideTailSlot(a.d_wide);
+        if (sum) atomicAdd(slot ? slot : a.d_tail_out, sum);
     }
 }
 

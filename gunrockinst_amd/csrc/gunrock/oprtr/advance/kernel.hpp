@@ -308,7 +308,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
             unsigned long long total = 0;
 #pragma unroll
             for (int w = 0; w < KernelPolicy::THREADS / util::kWaveSize; ++w) total += sh.wave_sum[w];
-            if (total) atomicAdd(a.d_tail_out, total);
+            if (total && a.d_tail_out) atomicAdd(a.d_tail_out, total);  // (nullptr: the caller does not want the count)
         }
         return;
     }

@@ -49,6 +49,12 @@ inline hipError_t SpinSync(hipStream_t stream)
     return rc;
 }
 
+// The calling workgroup's line of a "wide" tail (see WorkProgress::d_wide); nullptr stays nullptr.
+__device__ __forceinline__ unsigned long long *WideTailSlot(unsigned long long *d_wide)
+{
+    return d_wide ? d_wide + (blockIdx.x & 31u) * 16u : nullptr;
+}
+
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
     static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
@@ -57,6 +63,13 @@ struct WorkProgress {
     unsigned long long *d_tail = nullptr;  // [kSlots] packed (edges<<32 | vertices)
     int *d_overflow = nullptr;             // set when a writer ran out of queue capacity
     unsigned long long *d_sums = nullptr;  // [2] tail kernel: summed frontier lengths / edges
+    // "Wide" tail: kWideLines packed counters, 128 bytes apart.  Atomics on ONE address retire at ~80 per microsecond on
+    // MI355X (measured: 8192 wave-level adds = 103 us, tools/xcd_store_bench.hip), so kernels whose every workgroup reports
+    // a count (bottom-up sweep, fresh-flag pass) spread their adds over these lines and the host sums them.
+    static constexpr int kWideLines = 32;
+    static constexpr int kWideStride = 16;  // in 8-byte words
+    unsigned long long *d_wide = nullptr;
+    unsigned long long *h_wide = nullptr;
     unsigned long long *h_sums = nullptr;
     unsigned long long *h_tail = nullptr;  // pinned mirror for the per-step read-back
     int *h_overflow = nullptr;
@@ -72,6 +85,9 @@ struct WorkProgress {
         GR_CHECK(hipHostMalloc(&h_overflow, sizeof(int), hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
         GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
         GR_CHECK(hipHostMalloc(&h_sums, sizeof(unsigned long long) * 2, hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
+        GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress hipMalloc d_wide failed");
+        GR_CHECK(hipHostMalloc(&h_wide, sizeof(unsigned long long) * kWideLines * kWideStride, hipHostMallocDefault),
+                 "WorkProgress hipHostMalloc failed");
         return Reset(0);
     }
 
@@ -101,6 +117,32 @@ struct WorkProgress {
         GR_CHECK(SpinSync(stream), "WorkProgress GetTail sync failed");
         count = TailCount(h_tail[slot & 3]);
         edges = TailEdges(h_tail[slot & 3]);
+        return retval;
+    }
+
+    hipError_t ClearWide(hipStream_t stream)
+    {
+        return GRError(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride, stream),
+                       "WorkProgress ClearWide failed", __FILE__, __LINE__);
+    }
+    // Blocking read of one ring slot plus the wide counters; (count, edges) = their sum.
+    hipError_t GetTailWide(int slot, unsigned &count, unsigned &edges, hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        GR_CHECK(hipMemcpyAsync(h_tail + (slot & 3), d_tail + (slot & 3), sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, stream),
+                 "WorkProgress GetTailWide copy failed");
+        GR_CHECK(hipMemcpyAsync(h_wide, d_wide, sizeof(unsigned long long) * kWideLines * kWideStride, hipMemcpyDeviceToHost,
+                                stream),
+                 "WorkProgress GetTailWide copy failed");
+        GR_CHECK(SpinSync(stream), "WorkProgress GetTailWide sync failed");
+        unsigned long long c = TailCount(h_tail[slot & 3]), e = TailEdges(h_tail[slot & 3]);
+        for (int i = 0; i < kWideLines; ++i) {
+            c += TailCount(h_wide[i * kWideStride]);
+            e += TailEdges(h_wide[i * kWideStride]);
+        }
+        count = static_cast<unsigned>(c);
+        edges = static_cast<unsigned>(e);
         return retval;
     }
 
@@ -157,6 +199,9 @@ struct WorkProgress {
         if (h_overflow) GRError(hipHostFree(h_overflow), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
         if (d_sums) GRError(hipFree(d_sums), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (h_sums) GRError(hipHostFree(h_sums), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        if (d_wide) GRError(hipFree(d_wide), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        if (h_wide) GRError(hipHostFree(h_wide), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        d_wide = nullptr; h_wide = nullptr;
         d_sums = nullptr; h_sums = nullptr;
         d_tail = nullptr; d_overflow = nullptr; h_tail = nullptr; h_overflow = nullptr;
     }
