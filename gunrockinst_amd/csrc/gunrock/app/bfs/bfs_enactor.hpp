@@ -286,7 +286,6 @@ class BFSEnactor : public EnactorBase {
                 bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
                 bargs.d_wide = work_progress.d_wide;
-                if ((retval = work_progress.ClearWide(stream))) break;
                 const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
                 long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
                 const long long cap = max_grid_size > 0 ? max_grid_size
@@ -323,8 +322,7 @@ class BFSEnactor : public EnactorBase {
                     const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
                     long long fgrid = ((words64 + 15) / 16 + 3) / 4;  // 16 words per wave step, 4 waves per workgroup
                     if (fgrid > cu_count * 4) fgrid = cu_count * 4;
-                    if ((retval = work_progress.ClearWide(stream))) break;
-                    hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
+                        hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
                                        stream, ds->d_fresh, static_cast<long long>(problem->nodes),
                                        reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
                                        reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
@@ -359,8 +357,8 @@ class BFSEnactor : public EnactorBase {
         enactor_stats.iteration = iteration;
         if (retval) return retval;
 
-        bool overflow = false;
-        if ((retval = work_progress.CheckOverflow(overflow, stream))) return retval;
+        // (the loop's last read-back followed its last kernel, and SetTail cleared the flag of the previous search)
+        const bool overflow = work_progress.OverflowAtLastSync();
         if (overflow) {
             // same diagnosis as bfs_enactor.cuh:540-545
             retval = util::GRError(hipErrorInvalidConfiguration,

@@ -70,12 +70,7 @@ class SSSPEnactor : public EnactorBase {
         // tail words: [0] advance output (candidates), [1] near frontier, [2]/[3] far pile (ping-pong)
         unsigned long long *d_tail = work_progress.d_tail;
         unsigned long long *h_tail = work_progress.h_tail;
-        auto read_tails = [&]() -> hipError_t {
-            hipError_t rc = util::GRError(hipMemcpyAsync(h_tail, d_tail, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, stream),
-                                          "SSSPEnactor read tails failed", __FILE__, __LINE__);
-            if (rc) return rc;
-            return util::GRError(hipStreamSynchronize(stream), "SSSPEnactor sync failed", __FILE__, __LINE__);
-        };
+        auto read_tails = [&]() -> hipError_t { return work_progress.GetAll(stream); };
         unsigned *d_far_min = reinterpret_cast<unsigned *>(d_tail + 5);
         unsigned *h_far_min = reinterpret_cast<unsigned *>(h_tail + 5);
         auto arm_far_min = [&]() -> hipError_t {

@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
 
 #include <gunrock/util/error_utils.hpp>
 
@@ -55,6 +56,38 @@ __device__ __forceinline__ unsigned long long *WideTailSlot(unsigned long long *
     return d_wide ? d_wide + (blockIdx.x & 31u) * 16u : nullptr;
 }
 
+// Pinned, device-mapped host block the PublishKernel writes straight into (no copy engine, no blit kernel per word).
+struct HostMailbox {
+    unsigned long long seq;       // written last, system-scope release
+    unsigned long long tail[8];   // WorkProgress::d_tail
+    unsigned long long sums[2];   // WorkProgress::d_sums
+    unsigned long long wide;      // packed sum of the wide tail lines (which the kernel clears again)
+    unsigned long long overflow;  // *d_overflow
+    unsigned long long set_value; // staging word of WorkProgress::SetTail (host -> device)
+};
+
+// One wave: mirror the enactor's device words into the mailbox, fold + re-arm the wide tail, then publish `seq`.
+static __global__ void PublishKernel(const unsigned long long *d_tail, const unsigned long long *d_sums, unsigned long long *d_wide,
+                                     const int *d_overflow, HostMailbox *box, unsigned long long seq)
+{
+    const unsigned lane = threadIdx.x;
+    if (lane < 8) box->tail[lane] = d_tail[lane];
+    if (lane < 2) box->sums[lane] = d_sums[lane];
+    unsigned long long w = 0;
+    if (lane < 32) {
+        w = d_wide[lane * 16];
+        if (w) d_wide[lane * 16] = 0;
+    }
+    for (int o = 16; o; o >>= 1) w += __shfl_xor(w, o, 64);  // packed halves add independently (counts stay below 2^32)
+    if (lane == 0) {
+        box->wide = w;
+        box->overflow = static_cast<unsigned long long>(*d_overflow);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
     static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
@@ -65,14 +98,17 @@ struct WorkProgress {
     unsigned long long *d_sums = nullptr;  // [2] tail kernel: summed frontier lengths / edges
     // "Wide" tail: kWideLines packed counters, 128 bytes apart.  Atomics on ONE address retire at ~80 per microsecond on
     // MI355X (measured: 8192 wave-level adds = 103 us, tools/xcd_store_bench.hip), so kernels whose every workgroup reports
-    // a count (bottom-up sweep, fresh-flag pass) spread their adds over these lines and the host sums them.
+    // a count (bottom-up sweep, fresh-flag pass) spread their adds over these lines; PublishKernel folds and clears them.
     static constexpr int kWideLines = 32;
     static constexpr int kWideStride = 16;  // in 8-byte words
     unsigned long long *d_wide = nullptr;
-    unsigned long long *h_wide = nullptr;
-    unsigned long long *h_sums = nullptr;
-    unsigned long long *h_tail = nullptr;  // pinned mirror for the per-step read-back
-    int *h_overflow = nullptr;
+    // Host view.  Every blocking read-back of a BSP step is ONE tiny kernel that writes the mailbox in pinned host memory and
+    // a host spin on its sequence word: the previous form (one or two hipMemcpyAsync = blit kernels of 4-5 us each, then a
+    // stream query loop) cost ~20 us per level.
+    HostMailbox *box = nullptr;            // pinned + mapped
+    unsigned long long *h_sums = nullptr;  // = box->sums
+    unsigned long long *h_tail = nullptr;  // = box->tail
+    unsigned long long seq = 0;
 
     hipError_t Init()
     {
@@ -80,14 +116,14 @@ struct WorkProgress {
         if (d_tail) return retval;
         GR_CHECK(hipMalloc(&d_tail, sizeof(unsigned long long) * kSlots), "WorkProgress hipMalloc d_tail failed");
         GR_CHECK(hipMalloc(&d_overflow, sizeof(int)), "WorkProgress hipMalloc d_overflow failed");
-        GR_CHECK(hipHostMalloc(&h_tail, sizeof(unsigned long long) * kSlots, hipHostMallocDefault),
+        GR_CHECK(hipHostMalloc(reinterpret_cast<void **>(&box), sizeof(HostMailbox), hipHostMallocMapped),
                  "WorkProgress hipHostMalloc failed");
-        GR_CHECK(hipHostMalloc(&h_overflow, sizeof(int), hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
+        std::memset(box, 0, sizeof(HostMailbox));
+        h_tail = box->tail;
+        h_sums = box->sums;
         GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
-        GR_CHECK(hipHostMalloc(&h_sums, sizeof(unsigned long long) * 2, hipHostMallocDefault), "WorkProgress hipHostMalloc failed");
+        GR_CHECK(hipMemset(d_sums, 0, sizeof(unsigned long long) * 2), "WorkProgress memset failed");
         GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress hipMalloc d_wide failed");
-        GR_CHECK(hipHostMalloc(&h_wide, sizeof(unsigned long long) * kWideLines * kWideStride, hipHostMallocDefault),
-                 "WorkProgress hipHostMalloc failed");
         return Reset(0);
     }
 
@@ -96,67 +132,64 @@ struct WorkProgress {
         hipError_t retval = hipSuccess;
         GR_CHECK(hipMemsetAsync(d_tail, 0, sizeof(unsigned long long) * kSlots, stream), "WorkProgress memset failed");
         GR_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(int), stream), "WorkProgress memset failed");
+        GR_CHECK(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride, stream),
+                 "WorkProgress memset failed");
         return retval;
     }
 
     hipError_t SetTail(int slot, unsigned count, unsigned edges, hipStream_t stream)
     {
-        h_tail[slot & 3] = PackTail(count, edges);
-        return GRError(hipMemcpyAsync(d_tail + (slot & 3), h_tail + (slot & 3), sizeof(unsigned long long),
-                                      hipMemcpyHostToDevice, stream),
+        box->set_value = PackTail(count, edges);
+        box->overflow = 0;  // (a new search starts: forget the last search's flag)
+        return GRError(hipMemcpyAsync(d_tail + (slot & 3), &box->set_value, sizeof(unsigned long long), hipMemcpyHostToDevice, stream),
                        "WorkProgress SetTail failed", __FILE__, __LINE__);
     }
 
-    // Blocking read of one slot (the only host<->device sync of a BSP step).
+    // Mirror all device words into the mailbox and wait for them (the only host<->device sync of a BSP step).
+    hipError_t Sync(hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        ++seq;
+        hipLaunchKernelGGL(PublishKernel, dim3(1), dim3(64), 0, stream, d_tail, d_sums, d_wide, d_overflow, box, seq);
+        GR_CHECK(hipGetLastError(), "WorkProgress PublishKernel launch failed");
+        volatile unsigned long long *flag = &box->seq;
+        unsigned spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0x3FFu) == 0) {  // now and then: did the stream fail, or finish without us seeing the flag yet?
+                hipError_t rc = hipStreamQuery(stream);
+                if (rc == hipSuccess) {
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                    continue;
+                }
+                if (rc != hipErrorNotReady) return GRError(rc, "WorkProgress Sync: stream failed", __FILE__, __LINE__);
+            }
+        }
+        return retval;
+    }
+
+    // Blocking read of one slot.
     hipError_t GetTail(int slot, unsigned &count, unsigned &edges, hipStream_t stream)
     {
         hipError_t retval = hipSuccess;
-        GR_CHECK(hipMemcpyAsync(h_tail + (slot & 3), d_tail + (slot & 3), sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, stream),
-                 "WorkProgress GetTail copy failed");
-        GR_CHECK(SpinSync(stream), "WorkProgress GetTail sync failed");
+        GR_CHECK(Sync(stream), "WorkProgress GetTail sync failed");
         count = TailCount(h_tail[slot & 3]);
         edges = TailEdges(h_tail[slot & 3]);
         return retval;
     }
 
-    hipError_t ClearWide(hipStream_t stream)
-    {
-        return GRError(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride, stream),
-                       "WorkProgress ClearWide failed", __FILE__, __LINE__);
-    }
     // Blocking read of one ring slot plus the wide counters; (count, edges) = their sum.
     hipError_t GetTailWide(int slot, unsigned &count, unsigned &edges, hipStream_t stream)
     {
         hipError_t retval = hipSuccess;
-        GR_CHECK(hipMemcpyAsync(h_tail + (slot & 3), d_tail + (slot & 3), sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, stream),
-                 "WorkProgress GetTailWide copy failed");
-        GR_CHECK(hipMemcpyAsync(h_wide, d_wide, sizeof(unsigned long long) * kWideLines * kWideStride, hipMemcpyDeviceToHost,
-                                stream),
-                 "WorkProgress GetTailWide copy failed");
-        GR_CHECK(SpinSync(stream), "WorkProgress GetTailWide sync failed");
-        unsigned long long c = TailCount(h_tail[slot & 3]), e = TailEdges(h_tail[slot & 3]);
-        for (int i = 0; i < kWideLines; ++i) {
-            c += TailCount(h_wide[i * kWideStride]);
-            e += TailEdges(h_wide[i * kWideStride]);
-        }
-        count = static_cast<unsigned>(c);
-        edges = static_cast<unsigned>(e);
+        GR_CHECK(Sync(stream), "WorkProgress GetTailWide sync failed");
+        count = TailCount(h_tail[slot & 3]) + TailCount(box->wide);
+        edges = TailEdges(h_tail[slot & 3]) + TailEdges(box->wide);
         return retval;
     }
 
     // One blocking read of the whole ring + the tail kernel's outputs.
-    hipError_t GetAll(hipStream_t stream)
-    {
-        hipError_t retval = hipSuccess;
-        GR_CHECK(hipMemcpyAsync(h_tail, d_tail, sizeof(unsigned long long) * kSlots, hipMemcpyDeviceToHost, stream),
-                 "WorkProgress GetAll copy failed");
-        GR_CHECK(hipMemcpyAsync(h_sums, d_sums, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, stream),
-                 "WorkProgress GetAll copy failed");
-        GR_CHECK(SpinSync(stream), "WorkProgress GetAll sync failed");
-        return retval;
-    }
+    hipError_t GetAll(hipStream_t stream) { return Sync(stream); }
+
     // slot 7: grid-barrier counter (low word) and its timeout flag (high word) of the persistent levels kernel
     unsigned *BarrierCounter() { return reinterpret_cast<unsigned *>(d_tail + 7); }
     int *BarrierTimeout() { return reinterpret_cast<int *>(d_tail + 7) + 1; }
@@ -173,21 +206,20 @@ struct WorkProgress {
     hipError_t GetAux(unsigned &count, unsigned &edges, hipStream_t stream)
     {
         hipError_t retval = hipSuccess;
-        GR_CHECK(hipMemcpyAsync(h_tail + kAux, d_tail + kAux, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream),
-                 "WorkProgress GetAux copy failed");
-        GR_CHECK(SpinSync(stream), "WorkProgress GetAux sync failed");
+        GR_CHECK(Sync(stream), "WorkProgress GetAux sync failed");
         count = TailCount(h_tail[kAux]);
         edges = TailEdges(h_tail[kAux]);
         return retval;
     }
 
+    // Overflow flag as of the last Sync (every enactor loop ends on a Sync that follows its last kernel).
+    bool OverflowAtLastSync() const { return box->overflow != 0; }
+
     hipError_t CheckOverflow(bool &overflow, hipStream_t stream)
     {
         hipError_t retval = hipSuccess;
-        GR_CHECK(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost, stream),
-                 "WorkProgress CheckOverflow copy failed");
-        GR_CHECK(hipStreamSynchronize(stream), "WorkProgress CheckOverflow sync failed");
-        overflow = (*h_overflow != 0);
+        GR_CHECK(Sync(stream), "WorkProgress CheckOverflow sync failed");
+        overflow = OverflowAtLastSync();
         return retval;
     }
 
@@ -195,15 +227,10 @@ struct WorkProgress {
     {
         if (d_tail) GRError(hipFree(d_tail), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (d_overflow) GRError(hipFree(d_overflow), "WorkProgress hipFree failed", __FILE__, __LINE__);
-        if (h_tail) GRError(hipHostFree(h_tail), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
-        if (h_overflow) GRError(hipHostFree(h_overflow), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
+        if (box) GRError(hipHostFree(box), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
         if (d_sums) GRError(hipFree(d_sums), "WorkProgress hipFree failed", __FILE__, __LINE__);
-        if (h_sums) GRError(hipHostFree(h_sums), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
         if (d_wide) GRError(hipFree(d_wide), "WorkProgress hipFree failed", __FILE__, __LINE__);
-        if (h_wide) GRError(hipHostFree(h_wide), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
-        d_wide = nullptr; h_wide = nullptr;
-        d_sums = nullptr; h_sums = nullptr;
-        d_tail = nullptr; d_overflow = nullptr; h_tail = nullptr; h_overflow = nullptr;
+        d_tail = nullptr; d_overflow = nullptr; box = nullptr; h_tail = nullptr; h_sums = nullptr; d_sums = nullptr; d_wide = nullptr;
     }
 };
 
