@@ -176,11 +176,11 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipMalloc(&ds->d_inv_heads, sizeof(int2) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)),
                      "BFSProblem hipMalloc d_inv_heads failed");
         if (this->nodes > 0) {
-            long long grid = (static_cast<long long>(this->nodes) + 255) / 256;
-            if (grid > 4096) grid = 4096;
+            long long grid = (static_cast<long long>(this->nodes) + 3) / 4;  // one wave per vertex
+            if (grid > 8192) grid = 8192;
             hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<VertexId, SizeT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
                                this->graph_slices[0]->stream, d_inv_row_offsets, d_inv_column_indices,
-                               static_cast<long long>(this->nodes), ds->d_inv_heads);
+                               static_cast<long long>(this->nodes), ds->d_inv_heads, d_inv_row_offsets);
             GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
         }
         {

@@ -147,6 +147,7 @@ struct BottomUpArgs {
     unsigned long long *d_visited;          // visited bitmap, owner-updated
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
+    int head_skip = 2;                      // row entries the heads stand for: 2 = the first two (positional heads), 0 = ranked heads
     unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
 };
 
@@ -160,16 +161,48 @@ struct __attribute__((packed, aligned(4))) Quad {
 // first two in-neighbours of every vertex, -1 padded: the "adjacency head" (8 bytes per vertex, built once per
 // inverse graph).  Consecutive vertices have consecutive heads, so a wave's 64 lanes read 512 contiguous bytes,
 // where going to the CSR row costs a 64-byte line per vertex to use 4-8 bytes of it.
+// Which two?  The two in-neighbours of LARGEST degree among the first kHeadScan of the row: a bottom-up level asks "is any
+// in-neighbour in the frontier", and on a scale-free graph the well-connected neighbours are the ones discovered early, so
+// probing them first ends most searches at the heads (the first two by id were in the frontier far less often and sent
+// the vertex on to its CSR row: a 64-byte line for the offsets and another for the columns).  One wave per vertex.
+constexpr int kHeadScan = 512;
+
 template <typename VertexId, typename SizeT>
-__global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_column_indices, long long nodes, int2 *d_heads)
+__global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_column_indices, long long nodes, int2 *d_heads,
+                                 const SizeT *d_degree_offsets)  // row offsets the neighbour ids index (nullptr: rank by position)
 {
-    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
-    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v < nodes; v += stride) {
+    const unsigned lane = util::LaneId();
+    const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
+    for (long long v = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize; v < nodes; v += nwaves) {
         const SizeT b = d_row_offsets[v], e = d_row_offsets[v + 1];
-        int2 h;
-        h.x = (e - b > 0) ? d_column_indices[b] : -1;
-        h.y = (e - b > 1) ? d_column_indices[b + 1] : -1;
-        d_heads[v] = h;
+        const SizeT len = (e - b < kHeadScan) ? e - b : kHeadScan;
+        // key = (degree + 1) << 32 | id; 0 = nothing
+        unsigned long long k1 = 0, k2 = 0;
+        for (SizeT i = lane; i < len; i += util::kWaveSize) {
+            const VertexId u = d_column_indices[b + i];
+            // (no degree table -- the partitioned problem's columns are global ids -- : earlier position = larger key)
+            const unsigned long long deg = d_degree_offsets ? static_cast<unsigned long long>(d_degree_offsets[u + 1] - d_degree_offsets[u])
+                                                            : static_cast<unsigned long long>(kHeadScan - i);
+            const unsigned long long k = ((deg + 1) << 32) | static_cast<unsigned>(u);
+            if (k > k1) { k2 = k1; k1 = k; }
+            else if (k > k2) k2 = k;
+        }
+        unsigned long long best1 = k1;
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best1, o, util::kWaveSize);
+            best1 = other > best1 ? other : best1;
+        }
+        unsigned long long best2 = (k1 == best1) ? k2 : k1;  // (ids are distinct in a deduplicated row; a duplicate costs nothing)
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best2, o, util::kWaveSize);
+            best2 = other > best2 ? other : best2;
+        }
+        if (lane == 0) {
+            int2 h;
+            h.x = best1 ? static_cast<int>(static_cast<unsigned>(best1)) : -1;
+            h.y = best2 ? static_cast<int>(static_cast<unsigned>(best2)) : -1;
+            d_heads[v] = h;
+        }
     }
 }
 
@@ -253,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 }
             }
 
-            // ---- rows longer than the head continue in their CSR row from the third entry.  Only a few percent of the
+            // ---- rows longer than the head continue in their CSR row (from the third entry when the heads are the first two).  Only a few percent of the
             //      vertices get here, but nearly every WORD has one: walking the words one after another would put ~3
             //      dependent round trips per word back on the critical path.  Instead every lane takes ITS OWN next
             //      pending vertex (whatever word it sits in), so all pending vertices of the step advance together and
@@ -266,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 SizeT pos = 0, end = 0;
                 VertexId p_found = -1;
                 if (active) {
-                    pos = a.d_inv_row_offsets[v] + 2;
+                    pos = a.d_inv_row_offsets[v] + a.head_skip;
                     end = a.d_inv_row_offsets[v + 1];
                 }
                 // phase B: PROBE edges per round, up to SOLO_LIMIT edges per lane.  The round's in-neighbour ids were fetched

@@ -153,8 +153,10 @@ struct Pbfs : app::EnactorBase {
         }
         GR_CHECK(hipMalloc(&d_heads, sizeof(int2) * nl), "Pbfs hipMalloc failed");
         if (n_local > 0) {
-            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<int, int>), dim3((n_local + 255) / 256 < 4096 ? (n_local + 255) / 256 : 4096),
-                               dim3(256), 0, stream, d_row_offsets, d_col_indices, static_cast<long long>(n_local), d_heads);
+            // one wave per local vertex; the columns are global ids, so no degree table: the first two of the row
+            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<int, int>), dim3((n_local + 3) / 4 < 8192 ? (n_local + 3) / 4 : 8192),
+                               dim3(256), 0, stream, d_row_offsets, d_col_indices, static_cast<long long>(n_local), d_heads,
+                               static_cast<const int *>(nullptr));
             GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
         }
         // a rank forwards each global vertex at most once over the whole search
