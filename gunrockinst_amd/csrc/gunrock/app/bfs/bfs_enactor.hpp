@@ -60,9 +60,9 @@ class BFSEnactor : public EnactorBase {
     typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> LBAdvancePolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
-    // Persistent mid-size levels: 512-thread workgroups (one edge slot per thread: the level is latency-bound, so spread it
+    // Persistent mid-size levels: 1024-thread workgroups (one edge slot per thread: the level is latency-bound, so spread it
     // wide), at most one per CU, grid barrier between levels.
-    typedef oprtr::advance::KernelPolicy<512, 1, 1, oprtr::advance::LB> PersistentPolicy;
+    typedef oprtr::advance::KernelPolicy<1024, 1, 1, oprtr::advance::LB> PersistentPolicy;
     static constexpr int kTailEdgeLimit = 8192;  // default of BFSProblem::tail_edge_limit
     static constexpr int kTailMaxLevels = 4096;
 
@@ -90,7 +90,8 @@ class BFSEnactor : public EnactorBase {
     // applies the direction-optimizing rules).
     template <typename BFSProblem, typename BfsFunctor>
     hipError_t RunTail(BFSProblem *problem, long long &iteration, int &selector, unsigned &queue_length, unsigned &queue_edges,
-                       long long &unexplored_edges, hipStream_t stream, bool persistent = false, double switch_factor = 0.0)
+                       long long &unexplored_edges, hipStream_t stream, bool persistent = false, double switch_factor = 0.0,
+                       bool frontier_size_unknown = false)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
@@ -118,13 +119,14 @@ class BFSEnactor : public EnactorBase {
             // at least 16) and hand back to the host when the frontier outgrows it 8-fold; the host relaunches larger.
             long long grid = (static_cast<long long>(queue_edges) + PersistentPolicy::TILE - 1) / PersistentPolicy::TILE;
             if (grid < 16) grid = 16;
-            if (grid > cu_count) grid = cu_count;
+            if (grid > cu_count || frontier_size_unknown) grid = cu_count;  // (unknown: a kernel upstream wrote the frontier)
             long long limit = grid * PersistentPolicy::TILE * 8;
             if (grid == cu_count || limit > problem->persistent_edge_limit) limit = problem->persistent_edge_limit;
+            if (frontier_size_unknown) limit *= 4;  // all CUs are in: a larger level is still cheaper here than a round trip
             p.t.edge_limit = static_cast<SizeT>(limit);
             p.barrier.d_counter = work_progress.BarrierCounter();
             p.barrier.d_timeout = work_progress.BarrierTimeout();
-            p.min_edges = problem->tail_edge_limit / 4;  // hysteresis: only really small levels go back to one workgroup
+            p.solo_edges = problem->tail_edge_limit / 4;  // really small levels: workgroup 0 alone, no grid barrier
             p.unexplored_edges = unexplored_edges;
             p.switch_factor = switch_factor;
             if ((retval = oprtr::advance::LaunchPersistentLevels<PersistentPolicy, BFSProblem, BfsFunctor>(
@@ -231,8 +233,11 @@ class BFSEnactor : public EnactorBase {
                 if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
                 bottom_up = false;
                 snapshot_valid = false;
+                // The rest of the search usually only shrinks: one persistent launch takes the converted frontier (all CUs,
+                // grid barrier) and carries on alone in workgroup 0 once the levels are small -- no host round trip between.
                 if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
-                                                              unexplored_edges, stream)))
+                                                              unexplored_edges, stream, problem->persistent_edge_limit > 0, 0.0,
+                                                              true)))
                     break;
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 2);
                 continue;  // the loop re-examines the frontier the tail kernel left (empty, or too large for it)

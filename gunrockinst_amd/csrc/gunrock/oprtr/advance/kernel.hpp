@@ -467,7 +467,8 @@ template <typename VertexId, typename SizeT>
 struct PersistentArgs {
     TailArgs<VertexId, SizeT> t;
     GridBarrierState barrier;
-    SizeT min_edges;           // leave when a level has FEWER edge slots than this (the single-workgroup kernel is cheaper)
+    SizeT solo_edges;          // once a level has at most this many edge slots, workgroup 0 carries on ALONE (no more grid
+                               // barriers: the single-workgroup tail kernel inside this launch) until a level outgrows it
     long long unexplored_edges;  // direction-optimizing: leave when edges * switch_factor > unexplored (0 factor = never)
     double switch_factor;
 };
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
     long long unexplored = p.unexplored_edges;
     int done = 0;
     unsigned epoch = 0;
+    bool solo = (gridDim.x == 1);
     unsigned long long sum_len = 0, sum_edges = 0;
     for (;;) {
         if (threadIdx.x == 0) {
@@ -501,8 +503,13 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
         const SizeT len = static_cast<SizeT>(util::TailCount(tail));
         const SizeT edges = static_cast<SizeT>(util::TailEdges(tail));
         // every workgroup evaluates the same values => the same decision
-        if (len == 0 || edges > t.edge_limit || edges < p.min_edges || done >= t.max_levels) break;
+        if (len == 0 || edges > t.edge_limit || done >= t.max_levels) break;
         if (p.switch_factor > 0 && static_cast<double>(edges) * p.switch_factor > static_cast<double>(unexplored)) break;
+        if (!solo && edges <= p.solo_edges) {
+            if (blockIdx.x != 0) return;  // (the others are past the last barrier they take part in)
+            solo = true;
+        } else if (solo && gridDim.x > 1 && edges > p.solo_edges)
+            break;  // outgrew one workgroup and the others are gone: back to the host
 
         AdvanceArgs<VertexId, SizeT> a;
         a.in = t.queue[selector];
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
         slice.iteration = static_cast<VertexId>(iteration);
 
         const long long tiles = (static_cast<long long>(edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
-        const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
+        const long long per_block = solo ? tiles : (tiles + gridDim.x - 1) / gridDim.x;
         const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
         const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
         if (tile_begin < tile_end) {  // workgroup-uniform
@@ -527,7 +534,11 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
             __syncthreads();
             Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
         }
-        if (!GridBarrier(p.barrier, epoch)) break;  // (timeout: every workgroup sees the flag and leaves)
+        if (solo) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's stores and atomics have left the CU
+            __syncthreads();
+        } else if (!GridBarrier(p.barrier, epoch))
+            break;  // (timeout: every workgroup sees the flag and leaves)
         selector ^= 1;
         ++iteration;
         ++done;
