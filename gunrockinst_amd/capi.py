@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libgunrock.so")
+# GUNROCK_LIB_PATH: another build of the same library (tuning variants from tools/build_variant.sh); still no fallback.
+LIB_PATH = os.environ.get("GUNROCK_LIB_PATH") or os.path.join(_PKG, "lib", "libgunrock.so")
 _LIB = None
 
 # enum VertexIdType / SizeTType / ValueType / SrcMode (gunrock.h)

@@ -175,7 +175,10 @@ class BFSEnactor : public EnactorBase {
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
         if ((retval = work_progress.SetTail(0, queue_length, queue_edges, stream))) return retval;
 
-        const int conv_grid = cu_count * 4;
+#ifndef GRX_CONV_GRID_MULT
+#define GRX_CONV_GRID_MULT 2
+#endif
+        const int conv_grid = cu_count * GRX_CONV_GRID_MULT;
         const size_t mask_bytes = sizeof(unsigned) * static_cast<size_t>(problem->MaskWords() + 2);
         long long unexplored_edges = problem->edges;
         // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])

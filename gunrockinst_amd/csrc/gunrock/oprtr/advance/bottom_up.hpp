@@ -152,7 +152,10 @@ struct BottomUpArgs {
 };
 
 // 64-vertex bitmap words one wave takes per step of the bottom-up sweep (launch code sizes the grid from it)
-constexpr int kBottomUpStepWords = 8;
+#ifndef GRX_BU_STEP_WORDS
+#define GRX_BU_STEP_WORDS 8
+#endif
+constexpr int kBottomUpStepWords = GRX_BU_STEP_WORDS;
 
 struct __attribute__((packed, aligned(4))) Quad {
     int v[4];
