@@ -63,7 +63,13 @@ def main():
     backend = os.environ.get("GUNROCK_DIST_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GUNROCK_FORCE_PARTITIONED=1: run the vertex-partitioned level loop even at world 1 (measures its per-level overhead)
+    partitioned = world > 1 or os.environ.get("GUNROCK_FORCE_PARTITIONED") == "1"
+    if partitioned:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -73,7 +79,7 @@ def main():
     from gunrockinst_amd import devgraph
     ga.lib()  # fail loudly if the HIP library is missing
 
-    if world > 1:
+    if partitioned:
         from gunrockinst_amd import multi_gpu
         result = multi_gpu.bench(args, rank, world, local_rank)
     elif args.primitive == "cc":
@@ -84,9 +90,32 @@ def main():
         result = bench_single(args, torch, ga, devgraph, local_rank)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if partitioned:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_BFS_KERNELS = ("BfsResetKernel", "BitmapDiffKernel", "BitmapToQueueKernel", "BottomUpKernel", "FreshToBitmapKernel",
+                "LoadBalancedKernel", "PersistentLevelsKernel", "TailLevelsKernel", "QueueToBitmapKernel", "PublishKernel")
+
+
+def pmc_traffic_per_search():
+    """HBM-side bytes per BFS from the committed PMC passes of this same command (profiles/README.md): FETCH_SIZE and
+    WRITE_SIZE were collected in separate rocprofv3 runs and summed per kernel (KiB); searches = BfsResetKernel dispatches.
+    FETCH_SIZE is used RAW: on gfx950 it counts a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM)
+    and is uncalibrated for 4-byte gathers, so the true figure lies between fetch + write and 2 * fetch + write."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch_size.json")) as fh:
+            fetch = json.load(fh)
+        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_write_size.json")) as fh:
+            write = json.load(fh)
+        nf, nw = fetch["BfsResetKernel"]["dispatches"], write["BfsResetKernel"]["dispatches"]
+        fb = sum(fetch[k]["sum"] for k in _BFS_KERNELS if k in fetch) * 1024.0 / nf
+        wb = sum(write[k]["sum"] for k in _BFS_KERNELS if k in write) * 1024.0 / nw
+        return {"bytes": round(fb + wb), "fetch_raw": round(fb), "write": round(wb), "upper": round(2 * fb + wb),
+                "source": "profiles/r01_bench_pmc_{fetch,write}_size.json (separate rocprofv3 --pmc passes, per search)"}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
 
 
 def bench_single(args, torch, ga, devgraph, device_index):
@@ -172,8 +201,9 @@ def bench_single(args, torch, ga, devgraph, device_index):
         balg += 4.0 * ev + 20.0 * nv
     dom = max(by_kind, key=lambda kd: by_kind[kd][1]) if by_kind else 0
     achieved = balg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # GB/s over all operator launches of a BFS
+    pmc = pmc_traffic_per_search() if mode == 2 else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "frac": round(achieved / 8000.0, 5), "traffic": pmc["bytes"] if pmc else None, "traffic_detail": pmc,
                 "kernel": names.get(dom, str(dom)),
                 "kernel_share_of_device_time": round(by_kind[dom][1] / kernel_ms, 4) if kernel_ms else None,
                 "kernel_launches": by_kind[dom][0] if by_kind else 0,

@@ -80,6 +80,10 @@ _SIGNATURES = {
     "grx_graph_free": (None, [C.c_void_p]),
     "grx_rmat_seeded_device": (C.c_int, [C.c_int, C.c_longlong, C.c_longlong, C.c_uint64] + [C.c_double] * 4 +
                                [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "grx_coo_to_csr_sort": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_void_p]),
+    "grx_coo_to_csr_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "grx_coo_to_csr_free": (None, [C.c_void_p]),
     "grx_bfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
     "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -8,6 +8,7 @@
 #include <gunrock/csr.hpp>
 #include <gunrock/graphio/market.hpp>
 #include <gunrock/graphio/rmat.hpp>
+#include <gunrock/graphio/device_csr.hpp>
 #include <gunrock/graphio/rmat_device.hpp>
 #include <gunrock/graphio/utils.hpp>
 
@@ -123,6 +124,43 @@ int grx_rmat_seeded_device(int scale, long long first, long long count, uint64_t
     if (scale < 1 || scale > 30 || count < 0 || (count > 0 && (!d_rows || !d_cols))) return -1;
     return static_cast<int>(gunrock::graphio::SeededRmatDevice(scale, first, count, seed, a, b, c, d, d_rows, d_cols,
                                                                 static_cast<hipStream_t>(stream)));
+}
+
+struct grx_coo2csr {
+    gunrock::graphio::DeviceCooToCsr state;
+};
+
+int grx_coo_to_csr_sort(grx_coo2csr **handle, int rows, int nodes, long long pairs, const int *d_rows, const int *d_cols,
+                        int undirected, int parts, int rank, long long *edges_out, void *stream)
+{
+    if (!handle || rows < 0 || nodes < 1 || pairs < 0 || (pairs > 0 && (!d_rows || !d_cols)) || parts < 1 || rank < 0 ||
+        rank >= parts)
+        return -1;
+    const long long tuples = undirected ? 2 * pairs : pairs;
+    if (tuples >= (1ll << 31)) return -2;  // SIZET_INT contract of the C ABI (gunrock.h:33-37)
+    grx_coo2csr *h = new grx_coo2csr();
+    hipError_t rc = h->state.Sort(rows, nodes, pairs, d_rows, d_cols, undirected != 0, parts, rank, static_cast<hipStream_t>(stream));
+    if (rc != hipSuccess) {
+        h->state.Release();
+        delete h;
+        return static_cast<int>(rc);
+    }
+    if (edges_out) *edges_out = h->state.edges;
+    *handle = h;
+    return 0;
+}
+
+int grx_coo_to_csr_emit(grx_coo2csr *h, int *d_row_offsets, int *d_col_indices, void *stream)
+{
+    if (!h || !d_row_offsets || (h->state.edges > 0 && !d_col_indices)) return -1;
+    return static_cast<int>(h->state.Emit(d_row_offsets, d_col_indices, static_cast<hipStream_t>(stream)));
+}
+
+void grx_coo_to_csr_free(grx_coo2csr *h)
+{
+    if (!h) return;
+    h->state.Release();
+    delete h;
 }
 
 void grx_bfs_count_visited(int nodes, const int *row_offsets, const int *labels, long long *nodes_visited,

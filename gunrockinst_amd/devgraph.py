@@ -4,8 +4,8 @@ The reference builds every graph on the host with a serial rand() generator and 
 (reference gunrock/graphio/rmat.cuh:27-91, csr.cuh:247-340) -- minutes at scale-24.  Here the seeded R-MAT
 tuples come from the library's HIP generator (grx_rmat_seeded_device) and the COO -> CSR step
 (sort by (row, col), drop self loops and duplicates: the same graph Csr::FromCoo would give, all values 1)
-uses torch sort/unique as plumbing until the hand-written radix ingest lands.
-torch is used for device memory and sorting only; no traversal work happens here.
+is the library's hand-written device radix sort + scan (grx_coo_to_csr_*).
+torch is used for device memory only; no sorting or traversal work happens here.
 """
 import numpy as np
 import torch
@@ -38,32 +38,37 @@ def rmat_tuples_device(scale, pairs, seed=0x6772, a=0.55, b=0.2, c=0.2, d=0.05, 
     return rows, cols
 
 
-def csr_from_tuples_device(nodes, rows, cols, undirected=True, keep=None):
-    """(row, col) tuples on the GPU -> CSR on the GPU with Csr::FromCoo's graph semantics (values all 1).
+def csr_from_tuples_device(nodes, rows, cols, undirected=True, parts=1, rank=0):
+    """(row, col) int32 tuples on the GPU -> CSR on the GPU with Csr::FromCoo's graph semantics (values all 1), through the
+    library's hand-written radix sort / scan (grx_coo_to_csr_*; gunrock/graphio/device_csr.hpp).
 
-    `keep(row, col) -> bool mask` optionally restricts the directed tuples (used by the vertex-cut partitioner).
-    Returns int32 tensors (row_offsets[nodes+1], col_indices[m]).
+    parts > 1 builds rank's slice of the vertex-cut partition (local rows, global columns).
+    Returns int32 tensors (row_offsets[rows+1], col_indices[m]); torch only allocates the output arrays.
     """
-    r = rows.long()
-    c = cols.long()
-    if undirected:
-        r, c = torch.cat([r, c]), torch.cat([c, r])
-    mask = r != c
-    if keep is not None:
-        mask &= keep(r, c)
-    keys = (r[mask] << 32) | c[mask]
-    del r, c, mask
-    keys = torch.unique(keys)            # sorted ascending = (row, col) order, duplicates removed
-    src = (keys >> 32)
-    col_indices = (keys & 0xFFFFFFFF).int()
-    del keys
-    counts = torch.bincount(src, minlength=nodes)
-    del src
-    row_offsets = torch.zeros(nodes + 1, dtype=torch.int64, device=rows.device)
-    torch.cumsum(counts, 0, out=row_offsets[1:])
-    if int(row_offsets[-1]) >= 2 ** 31:
+    import ctypes as C
+    rows = rows.int().contiguous()
+    cols = cols.int().contiguous()
+    pairs = int(rows.shape[0])
+    n_rows = nodes if parts == 1 else ((nodes - rank + parts - 1) // parts if nodes > rank else 0)
+    torch.cuda.synchronize()
+    h, edges = C.c_void_p(), C.c_longlong()
+    rc = capi.lib().grx_coo_to_csr_sort(C.byref(h), n_rows, nodes, pairs, C.c_void_p(rows.data_ptr() if pairs else None),
+                                        C.c_void_p(cols.data_ptr() if pairs else None), int(bool(undirected)), parts, rank,
+                                        C.byref(edges), None)
+    if rc == -2:
         raise ValueError("graph exceeds the SIZET_INT contract of the C ABI")
-    return row_offsets.int().contiguous(), col_indices.contiguous()
+    if rc != 0:
+        raise RuntimeError("grx_coo_to_csr_sort failed (%d)" % rc)
+    try:
+        ro = torch.empty(n_rows + 1, dtype=torch.int32, device=rows.device)
+        ci = torch.empty(int(edges.value), dtype=torch.int32, device=rows.device)
+        torch.cuda.synchronize()
+        rc = capi.lib().grx_coo_to_csr_emit(h, C.c_void_p(ro.data_ptr()), C.c_void_p(ci.data_ptr() if edges.value else None), None)
+        if rc != 0:
+            raise RuntimeError("grx_coo_to_csr_emit failed (%d)" % rc)
+    finally:
+        capi.lib().grx_coo_to_csr_free(h)
+    return ro, ci
 
 
 def rmat_csr_device(scale, edge_factor=8, seed=0x6772, undirected=True, device="cuda"):

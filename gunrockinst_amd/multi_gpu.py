@@ -15,6 +15,7 @@ Compute never happens here: `engine` performs the local steps.  HipEngine drives
 (grx_pbfs_*).  The level loop is engine-agnostic so CPU tests can run it over gloo with a numpy test double.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -118,35 +119,47 @@ class PartitionedBfs:
         self.n_global, self.m_global = int(n_global), int(m_global)
         self.alpha, self.beta = float(alpha), float(beta)
         self.trace = []
+        self.profile = {} if os.environ.get("GUNROCK_PBFS_PROFILE") == "1" else None
 
     def run(self, src, direction_optimizing=True):
         eng, comm = self.engine, self.comm
         self.trace = []
-        glen, gedges = comm.all_reduce_sum(list(eng.reset(src)))
+        prof = self.profile          # None, or a dict phase -> seconds (GUNROCK_PBFS_PROFILE=1)
+        clock = time.perf_counter
+
+        def timed(name, fn, *a):
+            if prof is None:
+                return fn(*a)
+            t0 = clock()
+            out = fn(*a)
+            prof[name] = prof.get(name, 0.0) + clock() - t0
+            return out
+
+        glen, gedges = timed("all_reduce", comm.all_reduce_sum, list(timed("reset", eng.reset, src)))
         unexplored = self.m_global
         bottom_up = False
         levels = 0
         while glen > 0:
             if direction_optimizing and not bottom_up and gedges * self.alpha > unexplored:
-                eng.queue_to_bitmap()
+                timed("queue_to_bitmap", eng.queue_to_bitmap)
                 bottom_up = True
             elif direction_optimizing and bottom_up and glen * self.beta < self.n_global:
-                glen, gedges = comm.all_reduce_sum(list(eng.bitmap_to_queue()))
+                glen, gedges = timed("all_reduce", comm.all_reduce_sum, list(timed("bitmap_to_queue", eng.bitmap_to_queue)))
                 bottom_up = False
                 if glen == 0:
                     break
             unexplored -= gedges
             if bottom_up:
-                bitmap = eng.frontier_bitmap()
-                gathered = comm.all_gather(bitmap)
-                l, e = eng.bottom_up(gathered, bitmap.numel())
+                bitmap = timed("frontier_bitmap", eng.frontier_bitmap)
+                gathered = timed("all_gather", comm.all_gather, bitmap)
+                l, e = timed("bottom_up", eng.bottom_up, gathered, bitmap.numel())
             else:
-                send_counts, send = eng.advance_local()
-                recv_counts = comm.exchange_counts(send_counts)
-                recv = comm.all_to_all_v(send, send_counts, recv_counts)
-                l, e = eng.filter_received(recv)
+                send_counts, send = timed("advance_local", eng.advance_local)
+                recv_counts = timed("exchange_counts", comm.exchange_counts, send_counts)
+                recv = timed("all_to_all_v", comm.all_to_all_v, send, send_counts, recv_counts)
+                l, e = timed("filter_received", eng.filter_received, recv)
             self.trace.append(("bottom-up" if bottom_up else "top-down", glen, gedges))
-            glen, gedges = comm.all_reduce_sum([l, e])
+            glen, gedges = timed("all_reduce", comm.all_reduce_sum, [l, e])
             levels += 1
         return levels
 
@@ -230,32 +243,13 @@ class HipEngine:
 # ------------------------------------------------------------------------------------------------------------------
 # partitioned graph construction on the device
 # ------------------------------------------------------------------------------------------------------------------
-def partition_rmat_device(scale, edge_factor, seed, rank, parts, chunk_pairs=1 << 26, device="cuda"):
-    """Each rank generates the whole seeded tuple stream in chunks, keeps the directed tuples whose SOURCE it owns and
-    builds its local CSR (local row ids, global column ids) with Csr::FromCoo's graph semantics."""
+def partition_rmat_device(scale, edge_factor, seed, rank, parts, device="cuda"):
+    """Each rank generates the whole seeded tuple stream, and the library's device COO -> CSR step keeps the directed tuples
+    whose SOURCE the rank owns (grx_coo_to_csr_sort with parts / rank): local row ids, global column ids, Csr::FromCoo's
+    graph semantics."""
     from . import devgraph
-    n = 1 << scale
-    pairs = edge_factor << scale
-    kept = []
-    for first in range(0, pairs, chunk_pairs):
-        cnt = min(chunk_pairs, pairs - first)
-        rows, cols = devgraph.rmat_tuples_device(scale, cnt, seed, first=first, device=device)
-        r = torch.cat([rows, cols]).long()
-        c = torch.cat([cols, rows]).long()
-        del rows, cols
-        m = (r != c) & ((r % parts) == rank)
-        kept.append(((r[m] // parts) << 32) | c[m])
-        del r, c, m
-    keys = torch.unique(torch.cat(kept))
-    del kept
-    n_local = local_count(n, parts, rank)
-    src = keys >> 32
-    ci = (keys & 0xFFFFFFFF).int().contiguous()
-    del keys
-    counts = torch.bincount(src, minlength=n_local)
-    ro = torch.zeros(n_local + 1, dtype=torch.int64, device=device)
-    torch.cumsum(counts, 0, out=ro[1:])
-    return ro.int().contiguous(), ci
+    rows, cols = devgraph.rmat_tuples_device(scale, edge_factor << scale, seed, device=device)
+    return devgraph.csr_from_tuples_device(1 << scale, rows, cols, undirected=True, parts=parts, rank=rank)
 
 
 def partition_csr_host(row_offsets, col_indices, rank, parts):
@@ -357,6 +351,7 @@ def bench(args, rank, world, local_rank):
         single, _ = p.extract()
         p.close()
         parity = bool((single == full).all()) and int(gci.shape[0]) == m_global
+    bfs_runs = args.warmup + args.steps + len(set(used)) + 1
     eng.close()
 
     balg = 4.0 * edges_total + 20.0 * nodes_total
@@ -371,6 +366,8 @@ def bench(args, rank, world, local_rank):
                    "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend},
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_single_gpu": parity,
+        "level_loop_profile_ms_per_step": ({k: round(v * 1e3 / max(bfs_runs, 1), 4) for k, v in sorted(bfs.profile.items())}
+                                           if bfs.profile is not None else None),
         "roofline": {"bound": "hbm", "achieved": round(balg / wall / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": round(balg / wall / 1e9 / (8000.0 * world), 5), "traffic": None,
                      "note": "whole-step wall time (kernels + collectives), all ranks"},

@@ -56,6 +56,21 @@ void grx_graph_free(grx_graph *g);
 int grx_rmat_seeded_device(int scale, long long first, long long count, uint64_t seed,
                            double a, double b, double c, double d, int *d_rows, int *d_cols, void *stream);
 
+/* Device-side COO -> CSR with Csr::FromCoo's graph semantics (reference csr.cuh:247-340: stable sort by (row, col), self
+ * loops and duplicates dropped, trailing empty rows kept; `undirected` mirrors every tuple first, as the reference's
+ * loaders do, market.cuh:172-183).  Hand-written LSD radix sort + device-wide scan, all in HBM.
+ *   sort : d_rows / d_cols = `pairs` tuples on the device; rows = CSR rows to produce, nodes = vertex id space.
+ *          parts > 1 builds one rank's slice of a vertex-cut partition: only tuples whose source v has v mod parts == rank
+ *          are kept and stored under local row v div parts (ownership rule of reference problem_base.cuh:185-210).
+ *          Returns the number of CSR edges in *edges_out so the caller can allocate.
+ *   emit : writes row_offsets[rows + 1] and col_indices[edges] into caller-owned device arrays.
+ * Tuples must stay below 2^31 (SIZET_INT).  `stream` is a hipStream_t or NULL. */
+typedef struct grx_coo2csr grx_coo2csr;
+int grx_coo_to_csr_sort(grx_coo2csr **handle, int rows, int nodes, long long pairs, const int *d_rows, const int *d_cols,
+                        int undirected, int parts, int rank, long long *edges_out, void *stream);
+int grx_coo_to_csr_emit(grx_coo2csr *handle, int *d_row_offsets, int *d_col_indices, void *stream);
+void grx_coo_to_csr_free(grx_coo2csr *handle);
+
 /* ------------------------------------------------------------------------------------------------
  * BFS: BFSProblem + BFSEnactor (reference gunrock/app/bfs/bfs_problem.cuh:41-364, bfs_enactor.cuh:40-708)
  * ---------------------------------------------------------------------------------------------- */

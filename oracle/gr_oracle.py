@@ -100,6 +100,32 @@ def build_market(path, undirected=False, reversed_=False):
     return _take(c)
 
 
+class _Tuple(C.Structure):
+    _fields_ = [("row", C.c_int32), ("col", C.c_int32), ("val", C.c_int64)]
+
+
+def from_coo(nodes, rows, cols, undirected=False):
+    """Csr::FromCoo (csr.cuh:247-340) on explicit tuples; `undirected` appends the mirrored tuple right after each entry
+    like the reference's loaders (market.cuh:173-184).  Values are all 1."""
+    rows = np.asarray(rows, dtype=np.int32)
+    cols = np.asarray(cols, dtype=np.int32)
+    k = 2 if undirected else 1
+    t = (_Tuple * max(k * rows.shape[0], 1))()
+    arr = np.ctypeslib.as_array(t).view([("row", "<i4"), ("col", "<i4"), ("val", "<i8")]) if rows.shape[0] else None
+    if rows.shape[0]:
+        arr = arr.reshape(-1)
+        arr["val"][:] = 1
+        if undirected:
+            arr["row"][0::2], arr["col"][0::2] = rows, cols
+            arr["row"][1::2], arr["col"][1::2] = cols, rows
+        else:
+            arr["row"][:], arr["col"][:] = rows, cols
+    out = _Csr()
+    rc = lib().gro_csr_from_coo(t, int(nodes), int(k * rows.shape[0]), C.byref(out))
+    assert rc == 0
+    return _take(out)
+
+
 def rmat_reference(nodes, edges, undirected=False, a=0.55, b=0.2, c=0.2, d=0.05, srand=1):
     if srand is not None:
         lib().gro_srand(srand)

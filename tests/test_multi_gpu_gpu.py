@@ -38,7 +38,7 @@ def _worker(rank, world, port, backend, scale, dobfs, out):
 
     g = o.rmat_seeded(scale, 8 << scale)
     # device-side partition builder must agree with the host split of the oracle's CSR
-    ro_d, ci_d = mg.partition_rmat_device(scale, 8, 0x6772, rank, world, chunk_pairs=(8 << scale) // 3 + 1)
+    ro_d, ci_d = mg.partition_rmat_device(scale, 8, 0x6772, rank, world)
     ro_h, ci_h = mg.partition_csr_host(g.row_offsets, g.col_indices, rank, world)
     ok = bool((ro_d.cpu().numpy() == ro_h).all()) and bool((ci_d.cpu().numpy() == ci_h).all())
 
