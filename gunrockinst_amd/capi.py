@@ -84,6 +84,12 @@ _SIGNATURES = {
                                       C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_void_p]),
     "grx_coo_to_csr_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "grx_coo_to_csr_free": (None, [C.c_void_p]),
+    "grx_bc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "grx_bc_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_bc_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_bc_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float)]),
+    "grx_bc_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "grx_bc_destroy": (None, [C.c_void_p]),
     "grx_bfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
     "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -445,6 +451,73 @@ def gunrock_cc(nodes, row_offsets, col_indices, device=0):
     dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
     lib().gunrock_cc_func(C.byref(gout), C.byref(gin), cfg, dt)
     return _take_node_values(gout, nodes, np.int32)
+
+
+def gunrock_bc(nodes, row_offsets, col_indices, src=-1, queue_size=1.0, src_mode=SRC_MANUALLY, device=0):
+    """Call gunrock_bc_func as reference shared_lib_tests/test_bc.c does (src -1 = every vertex in turn); returns
+    (bc_values, ebc_values) as float32 arrays."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    gin = _graph_struct(nodes, ro, ci)
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.src_node, cfg.device, cfg.queue_size, cfg.src_mode = src, device, queue_size, src_mode
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_FLOAT)
+    lib().gunrock_bc_func(C.byref(gout), C.byref(gin), cfg, dt)
+    edges = int(ci.shape[0])
+    eptr = gout.edge_values
+    bc = _take_node_values(gout, nodes, np.float32)
+    if not eptr:
+        raise RuntimeError("gunrockinst_amd: the call produced no edge_values")
+    ebc = np.ctypeslib.as_array(C.cast(eptr, C.POINTER(C.c_float)), shape=(max(edges, 1),))[:edges].copy()
+    C.CDLL(None).free(C.c_void_p(eptr))
+    return bc, ebc
+
+
+class BcProblem:
+    """BCProblem + BCEnactor behind the handle ABI (grx_bc_*)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().grx_bc_create(C.byref(self._h), device), "grx_bc_create")
+        self.nodes = self.edges = 0
+        self._keep = None
+
+    def init(self, nodes, row_offsets, col_indices):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        self.nodes, self.edges = int(nodes), int(ci.shape[0])
+        _check(lib().grx_bc_init(self._h, self.nodes, self.edges, ro.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)),
+               "BCProblem::Init")
+        return self
+
+    def init_device(self, nodes, edges, d_row_offsets, d_col_indices):
+        self.nodes, self.edges = int(nodes), int(edges)
+        _check(lib().grx_bc_init_device(self._h, self.nodes, self.edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices)),
+               "BCProblem::Init (device)")
+        return self
+
+    def run(self, src=-1, max_grid_size=0, queue_sizing=1.0):
+        ms = C.c_float()
+        _check(lib().grx_bc_run(self._h, int(src), max_grid_size, float(queue_sizing), C.byref(ms)), "BCEnactor::Enact")
+        return float(ms.value)
+
+    def extract(self):
+        sig = np.empty(max(self.nodes, 1), dtype=np.float32)
+        bc = np.empty(max(self.nodes, 1), dtype=np.float32)
+        _check(lib().grx_bc_extract(self._h, sig.ctypes.data_as(C.c_void_p), bc.ctypes.data_as(C.c_void_p), None), "BCProblem::Extract")
+        return sig[:self.nodes], bc[:self.nodes]
+
+    def close(self):
+        if self._h:
+            lib().grx_bc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SsspProblem:

@@ -1,5 +1,5 @@
 // lib/stubs.hip -- entry points of gunrock.h that are outside this build's scope (SURVEY.md section 8:
-// BC, PageRank and TopK are other primitives).  Exported so programs written against the reference
+// PageRank and TopK are other primitives).  Exported so programs written against the reference
 // header keep linking; they fail loudly instead of computing anything.
 #include <gunrock/gunrock.h>
 
@@ -7,21 +7,16 @@
 
 extern "C" {
 
-void gunrock_bc_func(struct GunrockGraph *, const struct GunrockGraph *, struct GunrockConfig, struct GunrockDataType)
-{
-    std::fprintf(stderr, "[gunrock-mi355x] gunrock_bc_func is not built in this library (BFS/CC/SSSP path only).\n");
-}
-
 void gunrock_pr_func(struct GunrockGraph *, void *, void *, const struct GunrockGraph *, struct GunrockConfig,
                      struct GunrockDataType)
 {
-    std::fprintf(stderr, "[gunrock-mi355x] gunrock_pr_func is not built in this library (BFS/CC/SSSP path only).\n");
+    std::fprintf(stderr, "[gunrock-mi355x] gunrock_pr_func is not built in this library (BFS/CC/SSSP/BC only).\n");
 }
 
 void gunrock_topk_func(struct GunrockGraph *, void *, void *, void *, const struct GunrockGraph *, struct GunrockConfig,
                        struct GunrockDataType)
 {
-    std::fprintf(stderr, "[gunrock-mi355x] gunrock_topk_func is not built in this library (BFS/CC/SSSP path only).\n");
+    std::fprintf(stderr, "[gunrock-mi355x] gunrock_topk_func is not built in this library (BFS/CC/SSSP/BC only).\n");
 }
 
 }  // extern "C"

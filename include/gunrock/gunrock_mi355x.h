@@ -209,6 +209,22 @@ int grx_pbfs_labels(grx_pbfs *p, int **d_labels);
 void grx_pbfs_destroy(grx_pbfs *p);
 
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */
+/* ------------------------------------------------------------------------------------------------
+ * BC: BCProblem + BCEnactor (reference gunrock/app/bc/bc_problem.cuh:36-485, bc_enactor.cuh:36-634), the instantiation of
+ * the reference's C entry point: <int, int, float>, MARK_PREDECESSORS (bc_app.cu:61-66).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct grx_bc grx_bc;
+int grx_bc_create(grx_bc **out, int device);
+/* BCProblem::Init (bc_problem.cuh:203-330): host CSR in / device CSR borrowed */
+int grx_bc_init(grx_bc *p, int nodes, int edges, const int *row_offsets, const int *col_indices);
+int grx_bc_init_device(grx_bc *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices);
+/* The driver loop of run_bc (bc_app.cu:86-113): bc_values = 0; for src (or, when src == -1, every vertex in turn)
+ * Reset + Enact; bc_values *= 0.5.  elapsed_ms = device time of the whole loop. */
+int grx_bc_run(grx_bc *p, int src, int max_grid_size, double queue_sizing, float *elapsed_ms);
+/* BCProblem::Extract (bc_problem.cuh:140-192); sigmas are those of the LAST source; any pointer may be NULL */
+int grx_bc_extract(grx_bc *p, float *h_sigmas, float *h_bc_values, float *h_ebc_values);
+void grx_bc_destroy(grx_bc *p);
+
 const char *grx_version(void);
 
 #ifdef __cplusplus

@@ -536,3 +536,47 @@ int64_t gro_check_sssp_preds(const int32_t *ro, const int32_t *ci, const uint32_
     }
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * X5: betweenness centrality.  The reference validates against Boost's brandes_betweenness_centrality on an
+ * undirectedS graph for "all sources" (tests/bc/test_bc.cu:144-213) and against its own serial Brandes pass for one
+ * source (:224-300); its GPU drivers halve the accumulated values (bc_app.cu:112-113, test_bc.cu:443-444), which is
+ * what Boost does for undirected graphs.  Restated: Brandes' algorithm per source (BFS order, sigma counts, reverse
+ * accumulation delta[v] += sigma[v] / sigma[w] * (1 + delta[w]) over edges to the next level), bc[v] += delta[v]
+ * for v != source, everything in double, halved at the end.  src = -1: every vertex in turn.
+ * ---------------------------------------------------------------------------------------- */
+int gro_bc(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t src, double *bc_out, double *sigma_out)
+{
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nodes > 0 ? nodes : 1));
+    int32_t *label = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nodes > 0 ? nodes : 1));
+    double *sigma = (double *)malloc(sizeof(double) * (size_t)(nodes > 0 ? nodes : 1));
+    double *delta = (double *)malloc(sizeof(double) * (size_t)(nodes > 0 ? nodes : 1));
+    if (!order || !label || !sigma || !delta) { free(order); free(label); free(sigma); free(delta); return 1; }
+    for (int32_t v = 0; v < nodes; ++v) bc_out[v] = 0.0;
+    const int32_t first = (src == -1) ? 0 : src, last = (src == -1) ? nodes : src + 1;
+    for (int32_t s = first; s < last; ++s) {
+        for (int32_t v = 0; v < nodes; ++v) { label[v] = -1; sigma[v] = 0.0; delta[v] = 0.0; }
+        int32_t head = 0, tail = 0;
+        label[s] = 0; sigma[s] = 1.0; order[tail++] = s;
+        while (head < tail) {
+            const int32_t v = order[head++];
+            for (int32_t e = ro[v]; e < ro[v + 1]; ++e) {
+                const int32_t w = ci[e];
+                if (label[w] < 0) { label[w] = label[v] + 1; order[tail++] = w; }
+                if (label[w] == label[v] + 1) sigma[w] += sigma[v];
+            }
+        }
+        for (int32_t i = tail - 1; i >= 0; --i) {
+            const int32_t v = order[i];
+            for (int32_t e = ro[v]; e < ro[v + 1]; ++e) {
+                const int32_t w = ci[e];
+                if (label[w] == label[v] + 1) delta[v] += sigma[v] / sigma[w] * (1.0 + delta[w]);
+            }
+            if (v != s) bc_out[v] += delta[v];
+        }
+        if (sigma_out) for (int32_t v = 0; v < nodes; ++v) sigma_out[v] = sigma[v];
+    }
+    for (int32_t v = 0; v < nodes; ++v) bc_out[v] *= 0.5;
+    free(order); free(label); free(sigma); free(delta);
+    return 0;
+}

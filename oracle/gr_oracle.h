@@ -111,6 +111,12 @@ int64_t gro_check_sssp_preds(const int32_t *row_offsets, const int32_t *col_indi
                              const uint32_t *weights, int32_t nodes, int32_t src,
                              const uint32_t *dist, const int32_t *preds);
 
+/* X5: Brandes betweenness centrality, doubles, halved like the reference's GPU drivers and Boost's undirected form
+ * (tests/bc/test_bc.cu:144-300, bc_app.cu:112-113).  src = -1: all sources.  sigma_out (optional): path counts of the
+ * last source. */
+int gro_bc(const int32_t *row_offsets, const int32_t *col_indices, int32_t nodes, int32_t src,
+           double *bc_out, double *sigma_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,6 +188,16 @@ def cc_reference_schedule(g):
     return comp, int(count), int(ih.value), int(ij.value)
 
 
+def bc(g, src=-1):
+    """Brandes betweenness centrality (halved, reference convention); returns (bc float64[n], sigma of the last source)."""
+    out = np.empty(max(g.nodes, 1), dtype=np.float64)
+    sig = np.empty(max(g.nodes, 1), dtype=np.float64)
+    f64p = C.POINTER(C.c_double)
+    rc = lib().gro_bc(_p(g.row_offsets), _p(g.col_indices), g.nodes, int(src), out.ctypes.data_as(f64p), sig.ctypes.data_as(f64p))
+    assert rc == 0
+    return out[:g.nodes], sig[:g.nodes]
+
+
 def bfs_stats(g, labels):
     nv, ev = C.c_int64(), C.c_int64()
     labels = np.ascontiguousarray(labels, dtype=np.int32)

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("test_bfs", r"Node_ID.*2.*: Label.*1"),
     ("test_cc", r"Node_ID.*1.*: Component_ID.*0"),
     ("test_sssp", r"Node ID.*1.*: Label.*39.*: Predecessor.*0"),
+    ("test_bc", r"Node_ID.*0.*: BC.*0.500000"),
 ])
 def test_c_program_known_answer(name, regex):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), name, "-s"])

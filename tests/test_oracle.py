@@ -97,3 +97,14 @@ def test_sssp_vs_bfs_unit_weights(golden_dir):
     dist, preds = o.sssp(g, 3)
     assert np.array_equal(np.where(labels < 0, 0xFFFFFFFF, labels).astype(np.uint32), dist)
     assert o.check_sssp_preds(g, 3, dist, preds) == 0
+
+
+def test_bc_oracle_reproduces_reference_ctest_answer(golden):
+    # CMakeLists.txt:219-221: test_bc on the undirected 7-vertex graph prints BC 0.500000 for node 0 (all sources, halved)
+    f = golden["bc_undirected7"]
+    bc, _ = o.bc(o.Csr(7, f["row_offsets"], f["col_indices"]), -1)
+    assert abs(bc[0] - f["bc_node0"]) < 1e-12
+    assert ("%f" % bc[0]) == "0.500000"
+    # one source on a path 0-1-2: the middle vertex carries the dependency of the far end (1), halved
+    g = o.Csr(3, [0, 1, 3, 4], [1, 0, 2, 1])
+    assert o.bc(g, 0)[0].tolist() == [0.0, 0.5, 0.0]
