@@ -96,6 +96,7 @@ _SIGNATURES = {
     "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
+    "grx_bfs_set_head_pass": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "grx_bfs_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
@@ -293,6 +294,10 @@ class BfsProblem:
 
     def set_tuning(self, alpha=0.0, beta=0.0, lite_factor=-1.0, tail_edge_limit=-1):
         _check(lib().grx_bfs_set_tuning(self._h, alpha, beta, lite_factor, tail_edge_limit), "grx_bfs_set_tuning")
+        return self
+
+    def set_head_pass(self, min_edges=-1, max_edges=-1):
+        _check(lib().grx_bfs_set_head_pass(self._h, int(min_edges), int(max_edges)), "grx_bfs_set_head_pass")
         return self
 
     def set_persistent_limit(self, edge_limit):

@@ -188,37 +188,126 @@ class BFSEnactor : public EnactorBase {
         int cur_mask = 0;
         int selector = 0;
         long long iteration = 0;
+        // bottom-up sweep: frontier = d_frontier_mask[in_mask], finds -> d_frontier_mask[out_mask]; heads_only = probe the
+        // adjacency heads and stop
+        auto launch_bottom_up = [&](int in_mask, int out_mask, int heads_only) -> hipError_t {
+            oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
+            bargs.nodes = problem->nodes;
+            bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
+            bargs.d_inv_column_indices = ds->d_inv_column_indices;
+            bargs.d_inv_heads = ds->d_inv_heads;
+            oprtr::advance::BitmapLookup<VertexId> lookup{ds->d_frontier_mask[in_mask]};
+            bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[out_mask]);
+            bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
+            bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
+            bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
+            bargs.d_wide = work_progress.d_wide;
+            bargs.head_skip = 0;  // BFSProblem ranks the heads by degree: the row walk starts at its first entry
+            bargs.heads_only = heads_only;
+            const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
+            long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+            const long long cap = max_grid_size > 0 ? max_grid_size
+                : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
+            if (grid > cap) grid = cap;
+            if (grid < 1) grid = 1;
+            hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
+                               dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
+            return util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__);
+        };
+        // count-only top-down advance over the current queue: unvisited destinations get their d_fresh byte set
+        auto launch_count_only = [&](oprtr::advance::AdvanceArgs<VertexId, SizeT> args) -> hipError_t {
+            ds->lite = 1;
+            args.d_tail_out = nullptr;  // the advance's own count includes duplicates: not wanted
+            hipError_t rc = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor, true, true>(args, *ds, max_grid_size, stream,
+                                                                                                              oprtr::advance::V2V);
+            ds->lite = 0;
+            return rc;
+        };
+        // closing pass of a count-only level: bytes -> d_frontier_mask[0] (| d_merge), visited, labels, count (wide tail)
+        auto launch_fresh_pass = [&](const unsigned long long *d_before, const unsigned long long *d_merge) -> hipError_t {
+            const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
+            long long fgrid = ((words64 + 15) / 16 + 3) / 4;  // 16 words per wave step, 4 waves per workgroup
+            if (fgrid > cu_count * 4) fgrid = cu_count * 4;
+            hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0, stream,
+                               ds->d_fresh, static_cast<long long>(problem->nodes), reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
+                               d_before, reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), ds->d_labels,
+                               static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_wide,
+                               d_merge);
+            return util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__);
+        };
+        // frontier queue -> d_frontier_mask[0]
+        auto queue_to_mask = [&]() -> hipError_t {
+            hipError_t rc;
+            if (!snapshot_valid) {  // after a multi-level kernel the snapshot is several levels old: rebuild from the queue
+                if ((rc = util::GRError(hipMemsetAsync(ds->d_frontier_mask[0], 0, mask_bytes, stream),
+                                        "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
+                    return rc;
+                hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0, stream,
+                                   gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length), ds->d_frontier_mask[0]);
+                return util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__);
+            }
+            // the frontier is exactly what the last top-down level added to the visited bitmap (zero-degree discoveries
+            // included: they have no out-edges, so nobody can adopt them as parent)
+            const long long words64 = static_cast<long long>(problem->MaskWords()) / 2;
+            hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(conv_grid), dim3(256), 0, stream,
+                               reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
+                               reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
+                               reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), words64);
+            return util::GRError("BitmapDiffKernel launch failed", __FILE__, __LINE__);
+        };
         while (queue_length > 0) {
             const unsigned in_len = queue_length, in_edges = queue_edges;
             if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
 
             // ---- direction choice (Beamer's edge rule for down->up, the reference's vertex rule for up->down,
             //      dobfs_enactor.cuh:397,569) ----
-            if (dobfs && !bottom_up &&
+            if (dobfs && !bottom_up && !force_bottom_up && problem->head_pass_min_edges != 0 &&
+                static_cast<long long>(queue_edges) >= problem->HeadPassMin() &&
+                static_cast<long long>(queue_edges) <= problem->HeadPassMax() &&
+                queue_edges > static_cast<unsigned>(problem->tail_edge_limit) &&
+                static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges)) {
+                // ---- "heads, then the rest": a large level out of a sparse frontier is slow in either direction (top-down pays
+                //      one scattered store per edge, bottom-up one adjacency fetch per unvisited vertex).  First a bottom-up pass
+                //      that probes ONLY the adjacency heads -- the highest-degree in-neighbours, i.e. the likely members of such a
+                //      frontier: it settles most of the level's discoveries for the price of streaming the heads.  Then the
+                //      count-only top-down advance: its status screen now rejects every edge into a vertex the heads found, so the
+                //      scattered stores shrink to the remainder.
+                enactor_stats.total_queued += queue_length;
+                enactor_stats.total_edges_queued += queue_edges;
+                unexplored_edges -= queue_edges;
+                ds->iteration = static_cast<VertexId>(iteration);
+                if ((retval = queue_to_mask())) break;              // frontier -> d_frontier_mask[0]
+                if ((retval = launch_bottom_up(0, 1, 1))) break;    // finds -> d_frontier_mask[1] (the snapshot is spent)
+                oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
+                args.in = gs->frontier_queues[selector];
+                args.out = gs->frontier_queues[selector ^ 1];
+                args.in_len = static_cast<SizeT>(queue_length);
+                args.in_edges = static_cast<SizeT>(queue_edges);
+                args.d_row_offsets = gs->d_row_offsets;
+                args.d_column_indices = gs->d_column_indices;
+                args.d_tail_out = nullptr;
+                args.d_tail_clear = nullptr;
+                args.d_overflow = work_progress.d_overflow;
+                if ((retval = launch_count_only(args))) break;
+                // the advance did not touch the visited bitmap, so the bitmap itself is "visited before" for the closing pass
+                if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
+                                                reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]))))
+                    break;
+                cur_mask = 0;
+                force_bottom_up = true;
+                snapshot_valid = false;
+                if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
+                ++iteration;
+                if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+                if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 6);
+                continue;  // (selector unchanged: no queue was written)
+            } else if (dobfs && !bottom_up &&
                 (force_bottom_up || static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges))) {
                 if (force_bottom_up) {  // the count-only level already left its discoveries in d_frontier_mask[0]
                     force_bottom_up = false;
                     cur_mask = 0;
-                } else
-                // queue -> bitmap: the frontier is exactly what the last top-down level added to the visited bitmap
-                // (zero-degree discoveries included: they have no out-edges, so nobody can adopt them as parent).
-                // After a multi-level tail run the snapshot is several levels old: rebuild from the queue instead.
-                if (!snapshot_valid) {
-                    if ((retval = util::GRError(hipMemsetAsync(ds->d_frontier_mask[0], 0, mask_bytes, stream),
-                                                "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
-                        break;
-                    hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
-                                       stream, gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length),
-                                       ds->d_frontier_mask[0]);
-                    if ((retval = util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__))) break;
-                    cur_mask = 0;
-                } else {
-                    const long long words64 = static_cast<long long>(problem->MaskWords()) / 2;
-                    hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(conv_grid), dim3(256), 0, stream,
-                                       reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
-                                       reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
-                                       reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), words64);
-                    if ((retval = util::GRError("BitmapDiffKernel launch failed", __FILE__, __LINE__))) break;
+                } else {  // queue -> bitmap
+                    if ((retval = queue_to_mask())) break;
                     cur_mask = 0;
                 }
                 bottom_up = true;
@@ -283,27 +372,7 @@ class BFSEnactor : public EnactorBase {
             }
 
             if (bottom_up) {
-                oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
-                bargs.nodes = problem->nodes;
-                bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
-                bargs.d_inv_column_indices = ds->d_inv_column_indices;
-                bargs.d_inv_heads = ds->d_inv_heads;
-                oprtr::advance::BitmapLookup<VertexId> lookup{ds->d_frontier_mask[cur_mask]};
-                bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[cur_mask ^ 1]);
-                bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
-                bargs.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
-                bargs.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
-                bargs.d_wide = work_progress.d_wide;
-                bargs.head_skip = 0;  // BFSProblem ranks the heads by degree: the row walk starts at its first entry
-                const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
-                long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
-                const long long cap = max_grid_size > 0 ? max_grid_size
-                    : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
-                if (grid > cap) grid = cap;
-                if (grid < 1) grid = 1;
-                hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
-                                   dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
-                if ((retval = util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__))) break;
+                if ((retval = launch_bottom_up(cur_mask, cur_mask ^ 1, 0))) break;
                 cur_mask ^= 1;
             } else {
                 oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
@@ -322,23 +391,8 @@ class BFSEnactor : public EnactorBase {
                 const bool lite = dobfs && snapshot_valid && queue_edges > static_cast<unsigned>(problem->tail_edge_limit) &&
                                   static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges);
                 if (lite) {
-                    ds->lite = 1;
-                    args.d_tail_out = nullptr;  // the advance's own count includes duplicates: not wanted
-                    retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor, true, true>(
-                        args, *ds, max_grid_size, stream, oprtr::advance::V2V);
-                    ds->lite = 0;
-                    if (retval) break;
-                    const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
-                    long long fgrid = ((words64 + 15) / 16 + 3) / 4;  // 16 words per wave step, 4 waves per workgroup
-                    if (fgrid > cu_count * 4) fgrid = cu_count * 4;
-                        hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0,
-                                       stream, ds->d_fresh, static_cast<long long>(problem->nodes),
-                                       reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
-                                       reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
-                                       reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), ds->d_labels,
-                                       static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3),
-                                       work_progress.d_wide);
-                    if ((retval = util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__))) break;
+                    if ((retval = launch_count_only(args))) break;
+                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]), nullptr))) break;
                     cur_mask = 0;
                     force_bottom_up = true;
                     if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;

@@ -117,6 +117,19 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     float alpha = 10.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges (measured optimum 8..14 on R-MAT)
     float beta = 24.0f;   // bottom-up -> top-down when frontier_vertices * beta < nodes
     float lite_factor = 12.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
+    // direction-optimizing: a level that would run count-only or bottom-up and has between min and max frontier edges starts
+    // with a heads-only bottom-up pass.  -1 = automatic: edges/30 .. edges/7.8 (measured on R-MAT scale-24: below, the plain
+    // count-only level is cheaper; above, the frontier is dense enough for the full bottom-up sweep to win); min 0 = never,
+    // max 0 = no upper bound.
+    int head_pass_min_edges = -1;
+    int head_pass_max_edges = -1;
+    long long HeadPassMin() const { return head_pass_min_edges >= 0 ? head_pass_min_edges : static_cast<long long>(this->edges) / 30 + 1; }
+    long long HeadPassMax() const
+    {
+        if (head_pass_max_edges > 0) return head_pass_max_edges;
+        if (head_pass_max_edges == 0) return 1ll << 40;
+        return static_cast<long long>(static_cast<double>(this->edges) / 7.8);
+    }
     int persistent_edge_limit = 1 << 20;  // ... and up to this many inside the persistent multi-workgroup kernel (0 = off)
     int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 

@@ -60,7 +60,7 @@ template <typename VertexId>
 __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, unsigned long long *d_visited,
                                     const unsigned long long *d_visited_before, unsigned long long *d_frontier_out,
                                     VertexId *d_labels, VertexId label, unsigned long long *d_tail_out,
-                                    unsigned long long *d_wide)
+                                    unsigned long long *d_wide, const unsigned long long *d_merge = nullptr)
 {
     // One wave step = 1024 vertices: every lane loads its 16 flag bytes with ONE 16-byte load (the byte-per-lane version
     // issued 16x the load instructions and ran at 107 us for a 16 MiB map), squeezes them into 16 bits, and four
@@ -95,7 +95,7 @@ __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, uns
             d_labels[v0 + b] = label;
         }
         if (quad == 0 && in_range) {
-            d_frontier_out[my_word] = mask;
+            d_frontier_out[my_word] = d_merge ? (mask | d_merge[my_word]) : mask;  // (d_merge: this level's head-pass finds)
             d_visited[my_word] = seen | mask;  // authoritative
             count += static_cast<unsigned>(__popcll(mask));
         }
@@ -148,6 +148,7 @@ struct BottomUpArgs {
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
     int head_skip = 2;                      // row entries the heads stand for: 2 = the first two (positional heads), 0 = ranked heads
+    int heads_only = 0;                     // 1: probe the adjacency heads and stop (no CSR walk): a cheap first cut of a level
     unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
 };
 
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 }
             }
 
+            if (a.heads_only) more_bits = 0;
             // ---- rows longer than the head continue in their CSR row (from the third entry when the heads are the first two).  Only a few percent of the
             //      vertices get here, but nearly every WORD has one: walking the words one after another would put ~3
             //      dependent round trips per word back on the critical path.  Instead every lane takes ITS OWN next

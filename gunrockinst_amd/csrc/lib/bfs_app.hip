@@ -32,6 +32,7 @@ struct BfsRunner {
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual void SetPersistentLimit(int limit) = 0;
+    virtual void SetHeadPass(int min_edges, int max_edges) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
     virtual void Stats(long long &queued, long long &depth, double &duty, long long &launches, double &kernel_ms) = 0;
@@ -70,6 +71,11 @@ struct BfsRunnerT : BfsRunner {
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
     }
     void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
+    void SetHeadPass(int min_edges, int max_edges) override
+    {
+        problem.head_pass_min_edges = min_edges;
+        problem.head_pass_max_edges = max_edges;
+    }
     void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) override
     {
         if (alpha > 0) problem.alpha = alpha;
@@ -200,6 +206,13 @@ int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const in
 {
     if (!p) return -1;
     return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, alpha, beta));
+}
+
+int grx_bfs_set_head_pass(grx_bfs *p, int min_edges, int max_edges)
+{
+    if (!p || !p->runner || min_edges < -1 || max_edges < -1) return 1;
+    p->runner->SetHeadPass(min_edges, max_edges);
+    return 0;
 }
 
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit)

@@ -99,6 +99,11 @@ int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, i
  * kernel (one resident workgroup per CU, grid barrier between levels; 0 disables).  This is what the reference's
  * traversal_mode 1 (TWC advance for low-degree, high-diameter graphs, tests/bfs/test_bfs.cu:563-566) is for. */
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit);
+/* Direction-optimizing only: a level that would run count-only or bottom-up and has between `min_edges` and `max_edges`
+ * frontier edges starts with a bottom-up pass that probes only the adjacency heads (the highest-degree in-neighbours); the
+ * count-only top-down advance then handles what is left.  -1 = automatic bounds (edges/30 .. edges/7.8), min 0 = never,
+ * max 0 = no upper bound.  Results do not depend on it. */
+int grx_bfs_set_head_pass(grx_bfs *p, int min_edges, int max_edges);
 /* BFSProblem::Reset(src, frontier_type, queue_sizing) (reference bfs_problem.cuh:272-360) */
 int grx_bfs_reset(grx_bfs *p, int src, double queue_sizing);
 /* BFSEnactor::Enact(context, problem, src, max_grid_size, traversal_mode) (reference bfs_enactor.cuh:573-579);

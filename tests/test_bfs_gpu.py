@@ -266,3 +266,24 @@ def test_persistent_levels_kernel_parity(persistent_limit, tail_limit):
                     labels, preds = p.extract()
                     _check(g, int(src), labels, preds, p.stats())
             p.close()
+
+
+@pytest.mark.parametrize("min_edges,lite_factor,tail_limit", [(1, 1e9, 0), (1, 1e9, 100), (1000, 8.0, 8192), (1, 0.5, 64)])
+def test_head_pass_then_count_only_level_parity(min_edges, lite_factor, tail_limit):
+    # "heads, then the rest" levels (bottom-up pass over the adjacency heads + count-only top-down advance + merge) forced at
+    # small scale: labels and parents must equal the plain schedules'
+    for scale, ef in [(12, 8), (16, 8), (18, 16)]:
+        g = o.rmat_seeded(scale, ef << scale)
+        deg = np.diff(g.row_offsets)
+        srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist()
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph()
+            p.set_tuning(lite_factor=lite_factor, tail_edge_limit=tail_limit)
+            p.set_head_pass(min_edges, 0)
+            for src in srcs:
+                p.reset(int(src))
+                p.enact(int(src), traversal_mode=2)
+                labels, preds = p.extract()
+                _check(g, int(src), labels, preds, p.stats())
+            p.close()

@@ -7,10 +7,13 @@ scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 ro, ci = devgraph.rmat_csr_device(scale, 8)
 n, m = ro.shape[0] - 1, ci.shape[0]
 sources = [devgraph.largest_degree_source(ro)[0]] + devgraph.seeded_sources(ro, 64)
+hp = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 p = ga.BfsProblem(False, True, instrument=True).init_device(n, m, ro.data_ptr(), ci.data_ptr())
 p.set_inverse_graph()
+if hp >= 0: p.set_head_pass(hp, 0)
 q = ga.BfsProblem(False, True, instrument=False).init_device(n, m, ro.data_ptr(), ci.data_ptr())
 q.set_inverse_graph()
+if hp >= 0: q.set_head_pass(hp, 0)
 tot = {}
 for s in sources:
     p.reset(s); p.enact(s, traversal_mode=2)
