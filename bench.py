@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--alpha", type=float, default=0.0, help="direction switch tuning (0 = library default)")
     ap.add_argument("--beta", type=float, default=0.0)
     ap.add_argument("--lite-factor", type=float, default=-1.0)
+    ap.add_argument("--head-pass-min", type=int, default=-1, help="heads-then-rest level: min frontier edges (-1 auto, 0 off)")
+    ap.add_argument("--head-pass-max", type=int, default=-1, help="heads-then-rest level: max frontier edges (-1 auto, 0 none)")
     ap.add_argument("--traversal-mode", type=int, default=2,
                     help="0 = load-balanced top-down only, 2 = direction-optimizing (default)")
     return ap.parse_args()
@@ -134,6 +136,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     prob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
     prob.set_inverse_graph()          # the R-MAT graph is mirrored: its CSR is its own inverse
     prob.set_tuning(args.alpha, args.beta, args.lite_factor)
+    prob.set_head_pass(args.head_pass_min, args.head_pass_max)
     d_labels, _ = prob.device_results()
     labels_t = devgraph.as_tensor(d_labels, n)
 
@@ -177,6 +180,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob.init_device(n, m, ro.data_ptr(), ci.data_ptr())
     iprob.set_inverse_graph()
     iprob.set_tuning(args.alpha, args.beta, args.lite_factor)
+    iprob.set_head_pass(args.head_pass_min, args.head_pass_max)
     names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel",
              2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
              4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel"}
@@ -214,6 +218,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob.close()
 
     cpu = None
+    cpu_parallel = None
     parity = None
     if not args.no_cpu_baseline:
         from oracle import gr_oracle as o
@@ -234,6 +239,18 @@ def bench_single(args, torch, ga, devgraph, device_index):
         cpu = {"value": round(cpu_edges / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
                "sample": "%d serial deque BFS runs (oracle port of SimpleReferenceBfs) on the same scale-%d graph, "
                          "%.1f s CPU" % (args.cpu_baseline_runs, args.scale, cpu_s)}
+        # the stronger CPU baseline of SURVEY 8(d): level-synchronous OpenMP BFS on all host cores (not in the reference)
+        o.bfs_parallel(g, sources[0])  # thread start-up
+        par_edges, par_s, threads = 0, 0.0, 1
+        for k in range(max(args.cpu_baseline_runs, 4)):
+            s = sources[k % len(sources)]
+            t0 = time.perf_counter()
+            par_labels, threads = o.bfs_parallel(g, s)
+            par_s += time.perf_counter() - t0
+            par_edges += o.bfs_stats(g, par_labels)[1]
+        cpu_parallel = {"value": round(par_edges / (par_s * 1e6), 2), "unit": "MTEPS", "cores": threads, "kind": "port",
+                        "sample": "%d OpenMP level-synchronous BFS runs (oracle/gr_oracle.c gro_bfs_parallel) on the same "
+                                  "graph, %.2f s wall" % (max(args.cpu_baseline_runs, 4), par_s)}
     prob.close()
 
     depth = per_src[used[0]][2]
@@ -250,7 +267,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
         "enact_mteps": round(enact_mteps, 2), "topdown_only_enact_mteps": None if topdown_mteps is None else round(topdown_mteps, 2), "enact_ms_per_step": round(enact_ms / args.steps, 4),
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_oracle": parity,
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_parallel,
     }
 
 

@@ -6,6 +6,9 @@
  */
 #define _GNU_SOURCE
 #include "gr_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <limits.h>
 #include <stdio.h>
@@ -334,6 +337,75 @@ int32_t gro_bfs(const int32_t *ro, const int32_t *ci, int32_t nodes,
     if (preds) preds[src] = -1;
     free(fifo);
     return depth + 1;                                             /* test_bfs.cu:318 */
+}
+
+/* Level-synchronous top-down BFS on all host cores (OpenMP): NOT a restatement of anything in the reference (its CPU BFS
+ * is the serial loop above) -- the stronger CPU baseline SURVEY 8(d) asks to time next to it, with the thread count
+ * reported.  Labels are BFS depths, hence identical to gro_bfs; each vertex is claimed with one compare-and-swap. */
+int32_t gro_bfs_parallel(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t src, int32_t *labels, int32_t threads)
+{
+    if (nodes <= 0) return 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    int used = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+    }
+#else
+    const int used = 1;
+    (void)threads;
+#endif
+    int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)nodes);
+    int32_t *next = (int32_t *)malloc(sizeof(int32_t) * (size_t)nodes);
+    int64_t *counts = (int64_t *)calloc((size_t)used + 1, sizeof(int64_t));
+    int32_t **local = (int32_t **)calloc((size_t)used, sizeof(int32_t *));
+    int64_t *local_cap = (int64_t *)calloc((size_t)used, sizeof(int64_t));
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nodes; ++i) labels[i] = -1;
+    labels[src] = 0;
+    cur[0] = src;
+    int64_t cur_len = 1;
+    int32_t depth = 0;
+    while (cur_len > 0) {
+        const int32_t nd = depth + 1;
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            int64_t n = 0;
+#pragma omp for schedule(dynamic, 64)
+            for (int64_t i = 0; i < cur_len; ++i) {
+                const int32_t u = cur[i];
+                for (int32_t e = ro[u]; e < ro[u + 1]; ++e) {
+                    const int32_t w = ci[e];
+                    if (labels[w] == -1 && __sync_bool_compare_and_swap(&labels[w], -1, nd)) {
+                        if (n == local_cap[t]) {
+                            local_cap[t] = local_cap[t] ? 2 * local_cap[t] : 4096;
+                            local[t] = (int32_t *)realloc(local[t], sizeof(int32_t) * (size_t)local_cap[t]);
+                        }
+                        local[t][n++] = w;
+                    }
+                }
+            }
+            counts[t + 1] = n;
+#pragma omp barrier
+#pragma omp single
+            for (int k = 0; k < used; ++k) counts[k + 1] += counts[k];
+            memcpy(next + counts[t], local[t], sizeof(int32_t) * (size_t)n);
+        }
+        cur_len = counts[used];
+        counts[0] = 0;
+        int32_t *tmp = cur; cur = next; next = tmp;
+        if (cur_len > 0) depth = nd;
+    }
+    for (int k = 0; k < used; ++k) free(local[k]);
+    free(local); free(local_cap); free(counts); free(cur); free(next);
+    return used;
 }
 
 /* ------------------------------------------------------------------------------------------

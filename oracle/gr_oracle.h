@@ -111,6 +111,11 @@ int64_t gro_check_sssp_preds(const int32_t *row_offsets, const int32_t *col_indi
                              const uint32_t *weights, int32_t nodes, int32_t src,
                              const uint32_t *dist, const int32_t *preds);
 
+/* Level-synchronous BFS on `threads` host cores (0 = all), same labels as gro_bfs; returns the thread count used.
+ * A stronger CPU baseline than the reference's serial loop, reported separately. */
+int32_t gro_bfs_parallel(const int32_t *row_offsets, const int32_t *col_indices, int32_t nodes, int32_t src,
+                         int32_t *labels, int32_t threads);
+
 /* X5: Brandes betweenness centrality, doubles, halved like the reference's GPU drivers and Boost's undirected form
  * (tests/bc/test_bc.cu:144-300, bc_app.cu:112-113).  src = -1: all sources.  sigma_out (optional): path counts of the
  * last source. */

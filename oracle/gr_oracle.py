@@ -166,6 +166,13 @@ def bfs(g, src, want_preds=False):
     return labels, preds, int(depth)
 
 
+def bfs_parallel(g, src, threads=0):
+    """OpenMP level-synchronous BFS (labels identical to bfs()); returns (labels, threads used)."""
+    labels = np.empty(g.nodes, dtype=np.int32)
+    used = lib().gro_bfs_parallel(_p(g.row_offsets), _p(g.col_indices), g.nodes, src, _p(labels), int(threads))
+    return labels, int(used)
+
+
 def sssp(g, src, weights=None):
     w = np.ascontiguousarray(g.weights_u32 if weights is None else weights, dtype=np.uint32)
     dist = np.empty(g.nodes, dtype=np.uint32)

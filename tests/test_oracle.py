@@ -108,3 +108,13 @@ def test_bc_oracle_reproduces_reference_ctest_answer(golden):
     # one source on a path 0-1-2: the middle vertex carries the dependency of the far end (1), halved
     g = o.Csr(3, [0, 1, 3, 4], [1, 0, 2, 1])
     assert o.bc(g, 0)[0].tolist() == [0.0, 0.5, 0.0]
+
+
+def test_parallel_bfs_baseline_gives_the_serial_labels():
+    g = o.rmat_seeded(14, 8 << 14)
+    for src in (o.highest_degree_node(g)[0], 3, 12345):
+        ref, _, _ = o.bfs(g, src)
+        for threads in (1, 3, 0):
+            labels, used = o.bfs_parallel(g, src, threads)
+            assert np.array_equal(labels, ref)
+            assert used >= 1
