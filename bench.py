@@ -240,12 +240,14 @@ def bench_single(args, torch, ga, devgraph, device_index):
                "sample": "%d serial deque BFS runs (oracle port of SimpleReferenceBfs) on the same scale-%d graph, "
                          "%.1f s CPU" % (args.cpu_baseline_runs, args.scale, cpu_s)}
         # the stronger CPU baseline of SURVEY 8(d): level-synchronous OpenMP BFS on all host cores (not in the reference)
-        o.bfs_parallel(g, sources[0])  # thread start-up
+        # threads: the box's CPU share for one GPU is 16 cores even where the OS shows more
+        want = min(len(os.sched_getaffinity(0)), int(os.environ.get("GUNROCK_CPU_THREADS", "16")))
+        o.bfs_parallel(g, sources[0], want)  # thread start-up
         par_edges, par_s, threads = 0, 0.0, 1
         for k in range(max(args.cpu_baseline_runs, 4)):
             s = sources[k % len(sources)]
             t0 = time.perf_counter()
-            par_labels, threads = o.bfs_parallel(g, s)
+            par_labels, threads = o.bfs_parallel(g, s, want)
             par_s += time.perf_counter() - t0
             par_edges += o.bfs_stats(g, par_labels)[1]
         cpu_parallel = {"value": round(par_edges / (par_s * 1e6), 2), "unit": "MTEPS", "cores": threads, "kind": "port",
