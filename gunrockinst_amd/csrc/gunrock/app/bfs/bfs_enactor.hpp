@@ -204,6 +204,8 @@ class BFSEnactor : public EnactorBase {
             bargs.d_wide = work_progress.d_wide;
             bargs.head_skip = 0;  // BFSProblem ranks the heads by degree: the row walk starts at its first entry
             bargs.heads_only = heads_only;
+            bargs.d_never = reinterpret_cast<const unsigned long long *>(ds->d_never_mask);
+            bargs.d_head_base = ds->d_head_base;
             const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
             long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
             const long long cap = max_grid_size > 0 ? max_grid_size

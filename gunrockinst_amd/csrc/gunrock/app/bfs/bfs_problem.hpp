@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <gunrock/app/problem_base.hpp>
+#include <gunrock/graphio/device_csr.hpp>
 #include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
@@ -40,6 +41,18 @@ __global__ void NoInEdgeMaskKernel(const SizeT *d_inv_row_offsets, long long nod
         const unsigned long long m = __ballot(none);
         if (lane == 0) d_mask[w] = m;
     }
+}
+
+// vertices WITH in-edges per 64-vertex word (bits past the vertex count do not count)
+static __global__ void WithInEdgesCountKernel(const unsigned long long *d_never, long long nodes, long long words64, unsigned *d_counts)
+{
+    const long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= words64) return;
+    unsigned long long with_edges = ~d_never[w];
+    const long long first = w * 64;
+    if (first >= nodes) with_edges = 0;
+    else if (first + 64 > nodes) with_edges &= (1ull << (nodes - first)) - 1ull;
+    d_counts[w] = static_cast<unsigned>(__popcll(with_edges));
 }
 
 // Reset in one launch: 16-byte stores for labels / preds, the source patched in flight, queue entry 0 seeded.
@@ -107,6 +120,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         // direction-optimizing traversal (reference app/dobfs: d_frontier_map_in/out, dobfs_problem.cuh):
         unsigned *d_frontier_mask[2] = {nullptr, nullptr};  // 1 bit per vertex: current / next frontier
         unsigned *d_never_mask = nullptr;                   // vertices without in-edges: nothing can ever discover them
+        unsigned *d_head_base = nullptr;                    // compacted heads: first entry of every 64-vertex word (bottom_up.hpp)
         int2 *d_inv_heads = nullptr;                        // first two in-neighbours per vertex (bottom_up.hpp)
         const SizeT *d_inv_row_offsets = nullptr;           // in-neighbour CSR (CSC of the graph)
         const VertexId *d_inv_column_indices = nullptr;
@@ -150,6 +164,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                     if (ds->d_frontier_mask[i]) util::GRError(hipFree(ds->d_frontier_mask[i]), "BFSProblem hipFree d_frontier_mask failed", __FILE__, __LINE__);
                 if (ds->d_never_mask) util::GRError(hipFree(ds->d_never_mask), "BFSProblem hipFree d_never_mask failed", __FILE__, __LINE__);
                 if (ds->d_fresh) util::GRError(hipFree(ds->d_fresh), "BFSProblem hipFree d_fresh failed", __FILE__, __LINE__);
+                if (ds->d_head_base) util::GRError(hipFree(ds->d_head_base), "BFSProblem hipFree d_head_base failed", __FILE__, __LINE__);
                 if (ds->d_inv_heads) util::GRError(hipFree(ds->d_inv_heads), "BFSProblem hipFree d_inv_heads failed", __FILE__, __LINE__);
                 delete ds;
             }
@@ -188,14 +203,6 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (!ds->d_inv_heads)
             GR_CHECK(hipMalloc(&ds->d_inv_heads, sizeof(int2) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)),
                      "BFSProblem hipMalloc d_inv_heads failed");
-        if (this->nodes > 0) {
-            long long grid = (static_cast<long long>(this->nodes) + 3) / 4;  // one wave per vertex
-            if (grid > 8192) grid = 8192;
-            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<VertexId, SizeT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
-                               this->graph_slices[0]->stream, d_inv_row_offsets, d_inv_column_indices,
-                               static_cast<long long>(this->nodes), ds->d_inv_heads, d_inv_row_offsets);
-            GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
-        }
         {
             const long long words64 = static_cast<long long>(MaskWords()) / 2 + 1;
             long long grid = (words64 + 3) / 4;
@@ -204,8 +211,35 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                                this->graph_slices[0]->stream, d_inv_row_offsets, static_cast<long long>(this->nodes), words64,
                                reinterpret_cast<unsigned long long *>(ds->d_never_mask));
             GR_CHECK(hipGetLastError(), "NoInEdgeMaskKernel launch failed");
+            // heads are stored only for vertices that have in-edges: d_head_base[w] = such vertices before word w
+            if (!ds->d_head_base)
+                GR_CHECK(hipMalloc(&ds->d_head_base, sizeof(unsigned) * static_cast<size_t>(words64 + 1)), "BFSProblem hipMalloc d_head_base failed");
+            unsigned *d_counts = nullptr;
+            unsigned long long *d_scan_sums = nullptr;
+            GR_CHECK(hipMalloc(&d_counts, sizeof(unsigned) * static_cast<size_t>(words64 + 1)), "BFSProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_scan_sums, sizeof(unsigned long long) * static_cast<size_t>(graphio::ScanScratchWords(words64))),
+                     "BFSProblem hipMalloc failed");
+            hipLaunchKernelGGL(WithInEdgesCountKernel, dim3(static_cast<unsigned>((words64 + 255) / 256)), dim3(256), 0,
+                               this->graph_slices[0]->stream, reinterpret_cast<const unsigned long long *>(ds->d_never_mask),
+                               static_cast<long long>(this->nodes), words64, d_counts);
+            GR_CHECK(hipGetLastError(), "WithInEdgesCountKernel launch failed");
+            GR_CHECK(graphio::DeviceExclusiveScan<unsigned>(d_counts, ds->d_head_base, words64, d_scan_sums, this->graph_slices[0]->stream),
+                     "BFSProblem head-base scan failed");
             GR_CHECK(hipStreamSynchronize(this->graph_slices[0]->stream), "NoInEdgeMaskKernel failed");
+            GR_CHECK(hipFree(d_counts), "BFSProblem hipFree failed");
+            GR_CHECK(hipFree(d_scan_sums), "BFSProblem hipFree failed");
         }
+        if (this->nodes > 0) {
+            long long grid = (static_cast<long long>(this->nodes) + 3) / 4;  // one wave per vertex
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<VertexId, SizeT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               this->graph_slices[0]->stream, d_inv_row_offsets, d_inv_column_indices,
+                               static_cast<long long>(this->nodes), ds->d_inv_heads, d_inv_row_offsets,
+                               reinterpret_cast<const unsigned long long *>(ds->d_never_mask), ds->d_head_base);
+            GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(this->graph_slices[0]->stream), "BuildHeadsKernel failed");
+        }
+
         if (alpha_ > 0) alpha = alpha_;
         if (beta_ > 0) beta = beta_;
         direction_optimizing = true;

@@ -36,7 +36,7 @@ constexpr int kScanItems = 16;                      // per thread
 constexpr int kScanTile = kScanThreads * kScanItems;  // 4096 elements per workgroup
 
 // ---- device-wide exclusive scan of unsigned ints (sums may exceed 32 bits only in the totals: 64-bit block sums) ----
-__global__ __launch_bounds__(kScanThreads) void ScanTileSumsKernel(const unsigned *d_in, long long n, unsigned long long *d_sums)
+static __global__ __launch_bounds__(kScanThreads) void ScanTileSumsKernel(const unsigned *d_in, long long n, unsigned long long *d_sums)
 {
     __shared__ unsigned long long s_wave[kScanThreads / util::kWaveSize];
     const long long base = static_cast<long long>(blockIdx.x) * kScanTile;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kScanThreads) void ScanTileSumsKernel(const unsigne
 }
 
 // single workgroup: exclusive scan of up to a few hundred thousand 64-bit sums, in place; writes the total after the end
-__global__ __launch_bounds__(1024) void ScanSumsKernel(unsigned long long *d_sums, long long count)
+static __global__ __launch_bounds__(1024) void ScanSumsKernel(unsigned long long *d_sums, long long count)
 {
     __shared__ unsigned long long s_wave[1024 / util::kWaveSize];
     __shared__ unsigned long long s_carry;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void ScanSumsKernel(unsigned long long *d_sum
 
 // out[i] = tile offset + exclusive scan inside the tile (64-bit positions; OutT = unsigned or unsigned long long)
 template <typename OutT>
-__global__ __launch_bounds__(kScanThreads) void ScanApplyKernel(const unsigned *d_in, long long n, const unsigned long long *d_sums,
+static __global__ __launch_bounds__(kScanThreads) void ScanApplyKernel(const unsigned *d_in, long long n, const unsigned long long *d_sums,
                                                                 OutT *d_out)
 {
     __shared__ unsigned long long s_wave[kScanThreads / util::kWaveSize];
@@ -139,7 +139,7 @@ constexpr unsigned long long kSentinelKey = ~0ull;
 
 // parts > 1: keep only tuples whose source is owned by `rank` (owner = v mod parts) and store the LOCAL row v div parts
 // (the reference's ownership rule, problem_base.cuh:185-210); columns stay global.
-__global__ void MakeKeysKernel(const int *d_rows, const int *d_cols, long long pairs, int undirected, int col_bits, int nodes,
+static __global__ void MakeKeysKernel(const int *d_rows, const int *d_cols, long long pairs, int undirected, int col_bits, int nodes,
                                int parts, int rank, unsigned long long *d_keys)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -171,7 +171,7 @@ constexpr int kSortTile = kSortThreads * kSortRounds;     // 4096 keys per workg
 constexpr int kSortWaves = kSortThreads / util::kWaveSize;
 
 // hist[digit * tiles + tile] = keys of that tile with that digit
-__global__ __launch_bounds__(kSortThreads) void RadixHistogramKernel(const unsigned long long *d_keys, long long n, int shift,
+static __global__ __launch_bounds__(kSortThreads) void RadixHistogramKernel(const unsigned long long *d_keys, long long n, int shift,
                                                                      long long tiles, unsigned *d_hist)
 {
     __shared__ unsigned s_hist[256];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kSortThreads) void RadixHistogramKernel(const unsig
 }
 
 // stable scatter: out[offset[digit][tile] + rank among the tile's keys of that digit, in input order] = key
-__global__ __launch_bounds__(kSortThreads) void RadixScatterKernel(const unsigned long long *d_in, long long n, int shift,
+static __global__ __launch_bounds__(kSortThreads) void RadixScatterKernel(const unsigned long long *d_in, long long n, int shift,
                                                                    long long tiles, const unsigned long long *d_offsets,
                                                                    unsigned long long *d_out)
 {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kSortThreads) void RadixScatterKernel(const unsigne
 }
 
 // ---- dedup flags, CSR emission ----
-__global__ void FlagKernel(const unsigned long long *d_keys, long long n, unsigned long long sentinel, unsigned *d_keep)
+static __global__ void FlagKernel(const unsigned long long *d_keys, long long n, unsigned long long sentinel, unsigned *d_keep)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
     for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -245,7 +245,7 @@ __global__ void FlagKernel(const unsigned long long *d_keys, long long n, unsign
     }
 }
 
-__global__ void EmitCsrKernel(const unsigned long long *d_keys, const unsigned *d_keep, const unsigned long long *d_pos, long long n,
+static __global__ void EmitCsrKernel(const unsigned long long *d_keys, const unsigned *d_keep, const unsigned long long *d_pos, long long n,
                               int col_bits, int rows, long long edges, int *d_row_offsets, int *d_col_indices)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -263,7 +263,7 @@ __global__ void EmitCsrKernel(const unsigned long long *d_keys, const unsigned *
     }
 }
 
-__global__ void CloseOffsetsKernel(const unsigned long long *d_keys, const unsigned *d_keep, long long n, int col_bits, int rows,
+static __global__ void CloseOffsetsKernel(const unsigned long long *d_keys, const unsigned *d_keep, long long n, int col_bits, int rows,
                                    const unsigned long long *d_total, const unsigned long long *d_last_kept, int *d_row_offsets)
 {
     // d_last_kept: index of the last kept tuple + 1 (0 = none), produced by LastKeptKernel
@@ -275,7 +275,7 @@ __global__ void CloseOffsetsKernel(const unsigned long long *d_keys, const unsig
         d_row_offsets[r] = static_cast<int>(edges);
 }
 
-__global__ void LastKeptKernel(const unsigned *d_keep, long long n, unsigned long long *d_last_kept)
+static __global__ void LastKeptKernel(const unsigned *d_keep, long long n, unsigned long long *d_last_kept)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
     unsigned long long best = 0;

@@ -148,6 +148,10 @@ struct BottomUpArgs {
     unsigned long long *d_tail_out;
     unsigned long long *d_tail_clear;
     int head_skip = 2;                      // row entries the heads stand for: 2 = the first two (positional heads), 0 = ranked heads
+    // compacted heads: vertices without in-edges (bit set in d_never) have no head entry; a vertex's entry sits at
+    // d_head_base[word] + (number of vertices WITH in-edges before it in its 64-vertex word).  nullptr: indexed by vertex id.
+    const unsigned long long *d_never = nullptr;
+    const unsigned *d_head_base = nullptr;
     int heads_only = 0;                     // 1: probe the adjacency heads and stop (no CSR walk): a cheap first cut of a level
     unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
 };
@@ -173,7 +177,8 @@ constexpr int kHeadScan = 512;
 
 template <typename VertexId, typename SizeT>
 __global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_column_indices, long long nodes, int2 *d_heads,
-                                 const SizeT *d_degree_offsets)  // row offsets the neighbour ids index (nullptr: rank by position)
+                                 const SizeT *d_degree_offsets,  // row offsets the neighbour ids index (nullptr: rank by position)
+                                 const unsigned long long *d_never = nullptr, const unsigned *d_head_base = nullptr)
 {
     const unsigned lane = util::LaneId();
     const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
@@ -205,7 +210,12 @@ __global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_c
             int2 h;
             h.x = best1 ? static_cast<int>(static_cast<unsigned>(best1)) : -1;
             h.y = best2 ? static_cast<int>(static_cast<unsigned>(best2)) : -1;
-            d_heads[v] = h;
+            if (!d_head_base) {
+                d_heads[v] = h;
+            } else if (e > b) {  // compacted layout: only vertices with in-edges own an entry
+                const unsigned long long with_edges = ~d_never[v >> 6];
+                d_heads[d_head_base[v >> 6] + __popcll(with_edges & ((1ull << (v & 63)) - 1ull))] = h;
+            }
         }
     }
 }
@@ -253,13 +263,31 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
             // ---- phase H1: adjacency heads (coalesced 8 bytes per lane and word)
             int2 head[STEP_WORDS];
             unsigned open_bits = 0;  // bit j: this lane's vertex of word j is unvisited
+            if (a.d_head_base) {  // (kernel argument: wave-uniform) compacted heads: entry index from the never-mask ranks
+                unsigned long long my_with_edges = 0;
+                unsigned my_base = 0;
+                if (owns_word) {
+                    my_with_edges = ~a.d_never[my_word];
+                    my_base = a.d_head_base[my_word];
+                }
 #pragma unroll
-            for (int j = 0; j < STEP_WORDS; ++j) {
-                const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
-                const bool open = (open_mask >> lane) & 1ull;
-                open_bits |= static_cast<unsigned>(open) << j;
-                const long long v = (step * STEP_WORDS + j) * 64 + lane;
-                head[j] = a.d_inv_heads[open ? v : 0];
+                for (int j = 0; j < STEP_WORDS; ++j) {
+                    const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
+                    const bool open = (open_mask >> lane) & 1ull;
+                    open_bits |= static_cast<unsigned>(open) << j;
+                    const unsigned long long we = __shfl(my_with_edges, j, util::kWaveSize);
+                    const unsigned idx = __shfl(my_base, j, util::kWaveSize) + static_cast<unsigned>(__popcll(we & ((1ull << lane) - 1ull)));
+                    head[j] = a.d_inv_heads[open ? idx : 0u];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < STEP_WORDS; ++j) {
+                    const unsigned long long open_mask = __shfl(my_open, j, util::kWaveSize);
+                    const bool open = (open_mask >> lane) & 1ull;
+                    open_bits |= static_cast<unsigned>(open) << j;
+                    const long long v = (step * STEP_WORDS + j) * 64 + lane;
+                    head[j] = a.d_inv_heads[open ? v : 0];
+                }
             }
             // ---- phase H2: first in-neighbour of every open vertex
             bool hit[STEP_WORDS];
