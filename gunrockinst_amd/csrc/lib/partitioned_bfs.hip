@@ -324,6 +324,7 @@ struct Pbfs : app::EnactorBase {
         b.d_visited = reinterpret_cast<unsigned long long *>(ds.d_visited_mask);
         b.d_tail_out = work_progress.d_tail + 1;
         b.d_tail_clear = nullptr;
+        b.d_wide = work_progress.d_wide;  // per-workgroup counts spread over 32 lines, folded by the read-back
         ds.iteration = level;
         oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
         const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
@@ -334,7 +335,7 @@ struct Pbfs : app::EnactorBase {
         hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
                            dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
         GR_CHECK(hipGetLastError(), "BottomUpKernel launch failed");
-        if ((retval = work_progress.GetTail(1, frontier_len, frontier_edges, stream))) return retval;
+        if ((retval = work_progress.GetTailWide(1, frontier_len, frontier_edges, stream))) return retval;
         cur_mask ^= 1;
         ++level;
         *found = frontier_len;

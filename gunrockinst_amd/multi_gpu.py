@@ -120,8 +120,12 @@ class PartitionedBfs:
         self.alpha, self.beta = float(alpha), float(beta)
         self.trace = []
         self.profile = {} if os.environ.get("GUNROCK_PBFS_PROFILE") == "1" else None
+        self._send = None
 
-    def run(self, src, direction_optimizing=True):
+    def run(self, src, direction_optimizing=True, sticky_bottom_up=False):
+        """sticky_bottom_up: once the direction rule turns the search bottom-up it stays bottom-up to the end, on the
+        one-collective-per-level loop of _gather_levels (no all-reduce, no conversion back, no id exchange for the last
+        levels; those sweeps are cheap because almost nothing is unvisited by then)."""
         eng, comm = self.engine, self.comm
         self.trace = []
         prof = self.profile          # None, or a dict phase -> seconds (GUNROCK_PBFS_PROFILE=1)
@@ -135,7 +139,8 @@ class PartitionedBfs:
             prof[name] = prof.get(name, 0.0) + clock() - t0
             return out
 
-        glen, gedges = timed("all_reduce", comm.all_reduce_sum, list(timed("reset", eng.reset, src)))
+        local_len, local_edges = timed("reset", eng.reset, src)
+        glen, gedges = timed("all_reduce", comm.all_reduce_sum, [local_len, local_edges])
         unexplored = self.m_global
         bottom_up = False
         levels = 0
@@ -143,6 +148,8 @@ class PartitionedBfs:
             if direction_optimizing and not bottom_up and gedges * self.alpha > unexplored:
                 timed("queue_to_bitmap", eng.queue_to_bitmap)
                 bottom_up = True
+                if sticky_bottom_up:
+                    return levels + self._gather_levels(local_len, timed)
             elif direction_optimizing and bottom_up and glen * self.beta < self.n_global:
                 glen, gedges = timed("all_reduce", comm.all_reduce_sum, list(timed("bitmap_to_queue", eng.bitmap_to_queue)))
                 bottom_up = False
@@ -159,9 +166,59 @@ class PartitionedBfs:
                 recv = timed("all_to_all_v", comm.all_to_all_v, send, send_counts, recv_counts)
                 l, e = timed("filter_received", eng.filter_received, recv)
             self.trace.append(("bottom-up" if bottom_up else "top-down", glen, gedges))
+            local_len = l
             glen, gedges = timed("all_reduce", comm.all_reduce_sum, [l, e])
             levels += 1
         return levels
+
+
+    def _gather_levels(self, local_len, timed):
+        """Bottom-up levels until the frontier is empty; each level's ONE collective -- the all-gather of the per-rank
+        frontier bitmaps -- also carries each rank's frontier size in a trailing word, so termination needs no all-reduce."""
+        eng, comm = self.engine, self.comm
+        prof, clock = self.profile, time.perf_counter
+        levels = 0
+        while True:
+            bitmap = timed("frontier_bitmap", eng.frontier_bitmap)
+            wpr = int(bitmap.numel())
+            if self._send is None or self._send.numel() != wpr + 2 or self._send.device != bitmap.device:
+                self._send = torch.zeros(wpr + 2, dtype=torch.int32, device=bitmap.device)
+            t0 = clock()
+            self._send[:wpr].copy_(bitmap)
+            self._send[wpr] = int(local_len)
+            gathered = comm.all_gather(self._send)
+            total = int(gathered.view(comm.world, wpr + 2)[:, wpr].sum())
+            if prof is not None:
+                prof["all_gather"] = prof.get("all_gather", 0.0) + clock() - t0
+            if total == 0:
+                break
+            self.trace.append(("bottom-up", total, 0))
+            local_len, _ = timed("bottom_up", eng.bottom_up, gathered, wpr + 2)
+            levels += 1
+        return levels
+
+    def _timer(self):
+        prof, clock = self.profile, time.perf_counter
+
+        def timed(name, fn, *a):
+            if prof is None:
+                return fn(*a)
+            t0 = clock()
+            out = fn(*a)
+            prof[name] = prof.get(name, 0.0) + clock() - t0
+            return out
+        return timed
+
+    def run_gather(self, src):
+        """Bitmap-gather schedule from the first level on: every level is a bottom-up sweep.  Correct, one collective per
+        level -- and useless on a large graph: the first levels (a frontier of one vertex) make every unvisited vertex walk
+        its whole in-list (measured at scale-24 on one rank: 62 ms per search in the sweeps).  Kept for tests and tiny
+        graphs; run() switches to this loop only after the top-down levels (`sticky_bottom_up`)."""
+        timed = self._timer()
+        self.trace = []
+        local_len, _ = timed("reset", self.engine.reset, src)
+        timed("queue_to_bitmap", self.engine.queue_to_bitmap)
+        return self._gather_levels(local_len, timed)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -313,13 +370,19 @@ def bench(args, rank, world, local_rank):
     eng = HipEngine(n, world, rank, ro, ci, local_rank)
     bfs = PartitionedBfs(eng, comm, n, m_global)
 
+    # top-down levels exchange ids (all-to-all); from the first bottom-up level on, one all-gather per level to the end.
+    # GUNROCK_PBFS_SCHEDULE=exchange: the direction rules in both directions, an all-reduce per level (the first form).
+    gather = os.environ.get("GUNROCK_PBFS_SCHEDULE", "sticky") != "exchange"
+
+    def search(s):
+        return bfs.run(s, True, sticky_bottom_up=gather)
     for k in range(args.warmup):
-        bfs.run(sources[k % len(sources)])
+        search(sources[k % len(sources)])
     torch.cuda.synchronize()
     comm.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        bfs.run(sources[k % len(sources)])
+        search(sources[k % len(sources)])
     torch.cuda.synchronize()
     comm.barrier()
     wall = time.perf_counter() - t0
@@ -330,7 +393,7 @@ def bench(args, rank, world, local_rank):
     per_src = {}
     labels_t = eng.labels_tensor()
     for s in sorted(set(used)):
-        depth = bfs.run(s)
+        depth = search(s)
         vis = labels_t > -1
         nv, ev = comm.all_reduce_sum([int(vis.sum()), int(deg[vis].sum())])
         per_src[s] = (nv, ev, depth)
@@ -338,7 +401,7 @@ def bench(args, rank, world, local_rank):
     nodes_total = sum(per_src[s][0] for s in used)
 
     # parity: rank 0 runs the single-GPU engine on the whole graph for the first source and compares all labels
-    bfs.run(sources[0])
+    search(sources[0])
     full = assemble_labels(comm, eng.labels(), n)
     parity = None
     if rank == 0:
@@ -361,8 +424,10 @@ def bench(args, rank, world, local_rank):
         "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "BFS direction-optimizing, R-MAT scale-%d (%d pairs/vertex mirrored, seed 0x%x) "
-                               "vertex-partitioned over %d GPUs (owner = v mod %d), RCCL all-to-all / all-gather per level: "
-                               "n=%d, m=%d" % (args.scale, args.edge_factor, args.seed, world, world, n, m_global),
+                               "vertex-partitioned over %d GPUs (owner = v mod %d), %s: "
+                               "n=%d, m=%d" % (args.scale, args.edge_factor, args.seed, world, world,
+                                               "top-down levels: RCCL all-to-all of ids; from the first bottom-up level on one all-gather of the frontier bitmaps per level (sizes ride along)" if gather
+                                               else "RCCL all-to-all / all-gather + all-reduce per level", n, m_global),
                    "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend},
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_single_gpu": parity,

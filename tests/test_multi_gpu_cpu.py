@@ -42,7 +42,8 @@ def _worker(rank, world, port, scale, direction_optimizing, out):
     src, _ = o.highest_degree_node(g)
     ok = True
     for s in (src, int(np.nonzero(np.diff(g.row_offsets) > 0)[0][-1])):
-        levels = bfs.run(s, direction_optimizing=bool(direction_optimizing))
+        levels = (bfs.run_gather(s) if direction_optimizing == "gather" else bfs.run(s, True, sticky_bottom_up=True) if direction_optimizing == "sticky"
+                  else bfs.run(s, direction_optimizing=bool(direction_optimizing)))
         full = mg.assemble_labels(comm, eng.labels(), g.nodes)
         ref, _, depth = o.bfs(g, s)
         ok = ok and bool((full == ref).all()) and levels in (depth - 1, depth)
@@ -56,7 +57,7 @@ def _worker(rank, world, port, scale, direction_optimizing, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dobfs", [(2, False), (2, True), (3, True), (2, "always")])
+@pytest.mark.parametrize("world,dobfs", [(2, False), (2, True), (3, True), (2, "always"), (2, "gather"), (3, "gather"), (2, "sticky"), (3, "sticky")])
 def test_partitioned_bfs_over_gloo(tmp_path, world, dobfs):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), 9, dobfs, out), nprocs=world, join=True)

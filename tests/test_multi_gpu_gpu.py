@@ -49,7 +49,8 @@ def _worker(rank, world, port, backend, scale, dobfs, out):
     src, _ = o.highest_degree_node(g)
     deg = np.diff(g.row_offsets)
     for s in (src, int(np.nonzero(deg > 0)[0][-1]), int(np.nonzero(deg == 0)[0][0])):
-        levels = bfs.run(s, direction_optimizing=bool(dobfs))
+        levels = (bfs.run_gather(s) if dobfs == "gather" else bfs.run(s, True, sticky_bottom_up=True) if dobfs == "sticky"
+                  else bfs.run(s, direction_optimizing=bool(dobfs)))
         full = mg.assemble_labels(comm, eng.labels(), g.nodes)
         ref, _, depth = o.bfs(g, s)
         ok = ok and bool((full == ref).all()) and levels in (depth - 1, depth)
@@ -62,7 +63,8 @@ def _worker(rank, world, port, backend, scale, dobfs, out):
 
 
 @pytest.mark.parametrize("world,backend,dobfs", [(2, "gloo", False), (2, "gloo", True), (3, "gloo", "always"),
-                                                 (4, "gloo", True), (1, "nccl", True), (1, "nccl", False)])
+                                                 (4, "gloo", True), (1, "nccl", True), (1, "nccl", False),
+                                                 (2, "gloo", "gather"), (2, "gloo", "sticky"), (3, "gloo", "sticky"), (1, "nccl", "sticky")])
 def test_partitioned_bfs_hip_engine(tmp_path, world, backend, dobfs):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), backend, 15, dobfs, out), nprocs=world, join=True)
