@@ -60,7 +60,8 @@ template <typename VertexId, typename SizeT, bool PRED>
 __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *d_visited, const unsigned *d_never,
                                unsigned *d_snapshot, long long nodes,
                                long long mask_words, VertexId src, const SizeT *d_row_offsets,
-                               util::Frontier<VertexId, SizeT> queue0, SizeT *d_src_row)
+                               util::Frontier<VertexId, SizeT> queue0, SizeT *h_src_row, unsigned long long *h_src_seq,
+                               unsigned long long seq)
 {
     typedef __attribute__((ext_vector_type(4))) int V4;
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -95,8 +96,12 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
         queue0.v[0] = src;
         queue0.row_start[0] = begin;
         queue0.scan[0] = 0;
-        d_src_row[0] = begin;
-        d_src_row[1] = end;
+        // straight into pinned host memory, sequence word last: the host learns the source's degree while this kernel is
+        // still filling labels, and queues the first level behind it without a stream synchronisation
+        h_src_row[0] = begin;
+        h_src_row[1] = end;
+        __threadfence_system();
+        __hip_atomic_store(h_src_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -170,8 +175,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             }
             delete[] data_slices;
         }
-        if (h_src_row) util::GRError(hipHostFree(h_src_row), "BFSProblem hipHostFree failed", __FILE__, __LINE__);
-        if (d_src_row) util::GRError(hipFree(d_src_row), "BFSProblem hipFree failed", __FILE__, __LINE__);
+        if (h_src_box) util::GRError(hipHostFree(h_src_box), "BFSProblem hipHostFree failed", __FILE__, __LINE__);
     }
 
     // bitmaps are sized in whole 64-bit words: one wave owns one word in the bottom-up sweep
@@ -288,35 +292,55 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         GraphSlice<VertexId, SizeT, Value> *gs = this->graph_slices[0];
         DataSlice *ds = data_slices[0];
         hipStream_t stream = gs->stream;
-        if (!h_src_row) {
-            GR_CHECK(hipHostMalloc(&h_src_row, sizeof(SizeT) * 2, hipHostMallocDefault), "BFSProblem hipHostMalloc failed");
-            GR_CHECK(hipMalloc(&d_src_row, sizeof(SizeT) * 2), "BFSProblem hipMalloc d_src_row failed");
+        if (!h_src_box) {
+            GR_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_src_box), sizeof(SourceBox), hipHostMallocMapped), "BFSProblem hipHostMalloc failed");
+            h_src_box->seq = 0;
         }
         ds->iteration = 0;
-        h_src_row[0] = h_src_row[1] = 0;
         const bool valid = src >= 0 && src < this->nodes;
         const long long work = (static_cast<long long>(this->nodes) + 3) / 4;
         long long grid = (work + 255) / 256;
         if (grid > 2048) grid = 2048;
         if (grid < 1) grid = 1;
+        ++reset_seq;
         hipLaunchKernelGGL((BfsResetKernel<VertexId, SizeT, MARK_PREDECESSORS>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream,
                            ds->d_labels, ds->d_preds, ds->d_visited_mask, direction_optimizing ? ds->d_never_mask : nullptr,
                            direction_optimizing ? ds->d_frontier_mask[1] : nullptr, static_cast<long long>(this->nodes),
                            static_cast<long long>(MaskWords() + 2), valid ? src : static_cast<VertexId>(-1), gs->d_row_offsets,
-                           gs->frontier_queues[0], d_src_row);
+                           gs->frontier_queues[0], h_src_box->row, &h_src_box->seq, reset_seq);
         GR_CHECK(hipGetLastError(), "BfsResetKernel launch failed");
-        if (valid)
-            GR_CHECK(hipMemcpyAsync(h_src_row, d_src_row, sizeof(SizeT) * 2, hipMemcpyDeviceToHost, stream),
-                     "BFSProblem read source row failed");
-        GR_CHECK(hipStreamSynchronize(stream), "BFSProblem Reset sync failed");
-        src_row[0] = h_src_row[0];
-        src_row[1] = h_src_row[1];
+        // No synchronisation here: everything that follows runs on the same stream, and SourceDegree() waits for the one
+        // host-visible result (the source's row, which the kernel writes first).
+        src_row[0] = src_row[1] = 0;
+        src_row_pending = valid;
         source = src;
         return retval;
     }
 
     // Degree of the source, known after Reset (seeds the first packed tail).
-    SizeT SourceDegree() const { return src_row[1] - src_row[0]; }
+    SizeT SourceDegree()
+    {
+        if (src_row_pending) {
+            volatile unsigned long long *flag = &h_src_box->seq;
+            unsigned spins = 0, idle_checks = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != reset_seq) {
+                if ((++spins & 0x3FFu) == 0) {
+                    const hipError_t rc = hipStreamQuery(this->graph_slices[0]->stream);
+                    if (rc != hipSuccess && rc != hipErrorNotReady) {  // the reset kernel failed: report a zero-degree source
+                        util::GRError(rc, "BFSProblem Reset kernel failed", __FILE__, __LINE__);
+                        break;
+                    }
+                    if (rc == hipSuccess && ++idle_checks > 1000) break;  // stream drained and still no word: give up (degree 0)
+                }
+            }
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == reset_seq) {
+                src_row[0] = h_src_box->row[0];
+                src_row[1] = h_src_box->row[1];
+            }
+            src_row_pending = false;
+        }
+        return src_row[1] - src_row[0];
+    }
 
     hipError_t Extract(VertexId *h_labels, VertexId *h_preds)
     {
@@ -335,8 +359,13 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
 
     VertexId source = -1;
     SizeT src_row[2] = {0, 0};
-    SizeT *h_src_row = nullptr;  // pinned
-    SizeT *d_src_row = nullptr;
+    struct SourceBox {
+        unsigned long long seq;
+        SizeT row[2];
+    };
+    SourceBox *h_src_box = nullptr;  // pinned + mapped: written by BfsResetKernel
+    unsigned long long reset_seq = 0;
+    bool src_row_pending = false;
 };
 
 }  // namespace bfs
