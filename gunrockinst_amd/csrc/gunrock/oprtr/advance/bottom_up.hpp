@@ -43,7 +43,7 @@ __global__ void QueueToBitmapKernel(const VertexId *d_queue, SizeT length, unsig
 // ---- frontier bitmap = visited now XOR visited before the last top-down level (no atomics, 3 x n/8 bytes) ----
 // 218 K scattered atomicOr for the level-1 frontier of a scale-24 search cost 144 us (each is a 64-byte memory-side
 // request); two streaming bitmap reads cost ~3 us.
-static __global__ void BitmapDiffKernel(const unsigned long long *d_now, const unsigned long long *d_before,
+__attribute__((unused)) static __global__ void BitmapDiffKernel(const unsigned long long *d_now, const unsigned long long *d_before,
                                         unsigned long long *d_out, long long words)
 {
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
