@@ -208,6 +208,19 @@ class BFSEnactor : public EnactorBase {
             bargs.d_head_base = ds->d_head_base;
             const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
             long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+            // nearly finished search: few vertices can still be unvisited -> the compacting sweep (bottom_up.hpp)
+            const long long open_estimate = problem->with_in_edges - enactor_stats.total_queued;
+            if (problem->sparse_sweep_div > 0 && open_estimate * problem->sparse_sweep_div <= static_cast<long long>(problem->nodes)) {
+                const long long chunks = ((static_cast<long long>(problem->nodes) + 63) / 64 + 15) / 16;
+                long long sgrid = (chunks + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+                const long long scap = max_grid_size > 0 ? max_grid_size
+                    : util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
+                if (sgrid > scap) sgrid = scap;
+                if (sgrid < 1) sgrid = 1;
+                hipLaunchKernelGGL((oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
+                                   dim3(static_cast<unsigned>(sgrid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
+                return util::GRError("BottomUpSparseKernel launch failed", __FILE__, __LINE__);
+            }
             const long long cap = max_grid_size > 0 ? max_grid_size
                 : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
             if (grid > cap) grid = cap;

@@ -143,6 +143,10 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // max 0 = no upper bound.
     int head_pass_min_edges = -1;
     int head_pass_max_edges = -1;
+    long long with_in_edges = 0;  // vertices that have in-edges (only they can ever be discovered bottom-up)
+    // a bottom-up level runs the compacting sweep (BottomUpSparseKernel) when at most nodes / sparse_sweep_div such vertices
+    // can still be unvisited (0 = never)
+    int sparse_sweep_div = 16;
     long long HeadPassMin() const { return head_pass_min_edges >= 0 ? head_pass_min_edges : static_cast<long long>(this->edges) / 30 + 1; }
     long long HeadPassMax() const
     {
@@ -231,6 +235,12 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(graphio::DeviceExclusiveScan<unsigned>(d_counts, ds->d_head_base, words64, d_scan_sums, this->graph_slices[0]->stream),
                      "BFSProblem head-base scan failed");
             GR_CHECK(hipStreamSynchronize(this->graph_slices[0]->stream), "NoInEdgeMaskKernel failed");
+            {   // vertices that have in-edges = last base + last count (sizes the "nearly finished" test of the enactor)
+                unsigned last_base = 0, last_count = 0;
+                GR_CHECK(hipMemcpy(&last_base, ds->d_head_base + (words64 - 1), sizeof(unsigned), hipMemcpyDeviceToHost), "BFSProblem read failed");
+                GR_CHECK(hipMemcpy(&last_count, d_counts + (words64 - 1), sizeof(unsigned), hipMemcpyDeviceToHost), "BFSProblem read failed");
+                with_in_edges = static_cast<long long>(last_base) + last_count;
+            }
             GR_CHECK(hipFree(d_counts), "BFSProblem hipFree failed");
             GR_CHECK(hipFree(d_scan_sums), "BFSProblem hipFree failed");
         }

@@ -220,6 +220,83 @@ __global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_c
     }
 }
 
+// The CSR walk of one pending vertex per lane (wave-collective: phase C uses the whole wave).  Returns the parent found in the
+// current frontier or -1.
+//   phase B: PROBE edges per round, up to SOLO_LIMIT edges per lane.  The round's in-neighbour ids were fetched during the
+//            PREVIOUS round (software prefetch), so their frontier probes and the next round's id loads are in flight together:
+//            one memory round trip per round instead of two (PMC: this loop is a pure latency chain).
+//   phase C: rows still unresolved are swept by the whole wave, 256 in-edges per step.
+template <int PROBE, int SOLO_LIMIT, typename VertexId, typename SizeT, typename Lookup>
+__device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> &a, const Lookup &in_frontier, bool active, VertexId v,
+                                            unsigned lane)
+{
+    SizeT pos = 0, end = 0;
+    VertexId p_found = -1;
+    if (active) {
+        pos = a.d_inv_row_offsets[v] + a.head_skip;
+        end = a.d_inv_row_offsets[v + 1];
+    }
+    VertexId cur[PROBE];
+    auto fetch = [&](VertexId (&dst)[PROBE], SizeT from, bool wanted) {
+        if (wanted && from + PROBE <= end && (PROBE % 4) == 0) {
+#pragma unroll
+            for (int qd = 0; qd < PROBE / 4; ++qd) {  // 16-byte loads (rows are 4-byte aligned: gfx950 takes that)
+                const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + from + 4 * qd);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[4 * qd + k] = q.v[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PROBE; ++k)
+                dst[k] = (wanted && from + k < end) ? a.d_inv_column_indices[from + k] : static_cast<VertexId>(-1);
+        }
+    };
+    fetch(cur, pos, active && pos < end);
+    for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
+        if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
+        VertexId nxt[PROBE];
+        fetch(nxt, pos + PROBE, active && p_found < 0 && pos + PROBE < end && done + PROBE < SOLO_LIMIT);
+        bool fw[PROBE];
+#pragma unroll
+        for (int k = 0; k < PROBE; ++k) fw[k] = (active && p_found < 0 && cur[k] >= 0) ? in_frontier(cur[k]) : false;
+#pragma unroll
+        for (int k = 0; k < PROBE; ++k)
+            if (p_found < 0 && fw[k]) p_found = cur[k];
+        pos += PROBE;
+#pragma unroll
+        for (int k = 0; k < PROBE; ++k) cur[k] = nxt[k];
+    }
+    unsigned long long todo = __ballot(active && p_found < 0 && pos < end);
+    while (todo) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        SizeT p = __shfl(pos, leader, util::kWaveSize);
+        const SizeT e = __shfl(end, leader, util::kWaveSize);
+        VertexId hit_parent = -1;
+        for (; p < e && hit_parent < 0; p += 4 * util::kWaveSize) {  // 4 loads in flight per lane
+            VertexId u[4];
+            bool h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const SizeT mine = p + static_cast<SizeT>(k * util::kWaveSize + lane);
+                u[k] = (mine < e) ? a.d_inv_column_indices[mine] : static_cast<VertexId>(-1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = (u[k] >= 0) ? in_frontier(u[k]) : false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long hm = __ballot(h[k]);
+                if (hm && hit_parent < 0) hit_parent = __shfl(u[k], __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
+            }
+        }
+        if (static_cast<int>(lane) == leader) {
+            p_found = hit_parent;
+            pos = end;
+        }
+        todo &= todo - 1;
+    }
+    return p_found;
+}
+
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
 __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
@@ -329,74 +406,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 const int jl = active ? (__ffs(more_bits) - 1) : 0;
                 more_bits &= more_bits - 1;
                 const VertexId v = static_cast<VertexId>((step * STEP_WORDS + jl) * 64 + lane);
-                SizeT pos = 0, end = 0;
-                VertexId p_found = -1;
-                if (active) {
-                    pos = a.d_inv_row_offsets[v] + a.head_skip;
-                    end = a.d_inv_row_offsets[v + 1];
-                }
-                // phase B: PROBE edges per round, up to SOLO_LIMIT edges per lane.  The round's in-neighbour ids were fetched
-                // during the PREVIOUS round (software prefetch), so their frontier probes and the next round's id loads are in
-                // flight together: one memory round trip per round instead of two (PMC: this loop is a pure latency chain).
-                VertexId cur[PROBE];
-                auto fetch = [&](VertexId (&dst)[PROBE], SizeT from, bool wanted) {
-                    if (wanted && from + PROBE <= end && (PROBE % 4) == 0) {
-#pragma unroll
-                        for (int qd = 0; qd < PROBE / 4; ++qd) {  // 16-byte loads (rows are 4-byte aligned: gfx950 takes that)
-                            const Quad q = *reinterpret_cast<const Quad *>(a.d_inv_column_indices + from + 4 * qd);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) dst[4 * qd + k] = q.v[k];
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < PROBE; ++k)
-                            dst[k] = (wanted && from + k < end) ? a.d_inv_column_indices[from + k] : static_cast<VertexId>(-1);
-                    }
-                };
-                fetch(cur, pos, active && pos < end);
-                for (int done = 0; done < SOLO_LIMIT; done += PROBE) {
-                    if (__ballot(active && p_found < 0 && pos < end) == 0) break;  // wave-uniform
-                    VertexId nxt[PROBE];
-                    fetch(nxt, pos + PROBE, active && p_found < 0 && pos + PROBE < end && done + PROBE < SOLO_LIMIT);
-                    bool fw[PROBE];
-#pragma unroll
-                    for (int k = 0; k < PROBE; ++k) fw[k] = (active && p_found < 0 && cur[k] >= 0) ? in_frontier(cur[k]) : false;
-#pragma unroll
-                    for (int k = 0; k < PROBE; ++k)
-                        if (p_found < 0 && fw[k]) p_found = cur[k];
-                    pos += PROBE;
-#pragma unroll
-                    for (int k = 0; k < PROBE; ++k) cur[k] = nxt[k];
-                }
-                // phase C: rows still unresolved are swept by the whole wave, 64 in-edges per step
-                unsigned long long todo = __ballot(active && p_found < 0 && pos < end);
-                while (todo) {
-                    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-                    SizeT p = __shfl(pos, leader, util::kWaveSize);
-                    const SizeT e = __shfl(end, leader, util::kWaveSize);
-                    VertexId hit_parent = -1;
-                    for (; p < e && hit_parent < 0; p += 4 * util::kWaveSize) {  // 256 in-edges per step, 4 loads in flight per lane
-                        VertexId u[4];
-                        bool h[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const SizeT mine = p + static_cast<SizeT>(k * util::kWaveSize + lane);
-                            u[k] = (mine < e) ? a.d_inv_column_indices[mine] : static_cast<VertexId>(-1);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) h[k] = (u[k] >= 0) ? in_frontier(u[k]) : false;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const unsigned long long hm = __ballot(h[k]);
-                            if (hm && hit_parent < 0) hit_parent = __shfl(u[k], __ffsll(static_cast<long long>(hm)) - 1, util::kWaveSize);
-                        }
-                    }
-                    if (static_cast<int>(lane) == leader) {
-                        p_found = hit_parent;
-                        pos = end;
-                    }
-                    todo &= todo - 1;
-                }
+                const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane);
                 const bool late = active && p_found >= 0;
                 if (late) {
                     slice.d_labels[v] = new_label;
@@ -434,6 +444,141 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     unsigned long long packed = util::PackTail(found_count, found_edges);
     packed = util::WaveSum(packed);
     if (lane == 0) s_total[tid / util::kWaveSize] = packed;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) sum += s_total[i];
+        unsigned long long *slot = util::WideTailSlot(a.d_wide);
+        if (sum) atomicAdd(slot ? slot : a.d_tail_out, sum);
+    }
+}
+
+// ---- bottom-up sweep for a nearly finished search (few unvisited vertices) ----
+// The dense kernel runs its unrolled 8-word pipeline for every step that holds ANY unvisited vertex; late in a search that is
+// every step (a few hundred thousand unvisited vertices spread over 262 K words) with a dozen busy lanes each, so a level
+// costs the same ~25 us whether it finds 3 M vertices or 300.  Here a wave takes 16 words (1024 vertices), compacts their
+// unvisited vertices onto its lanes (prefix sums of the words' popcounts; lane k takes the k-th one), and runs ONE pass of
+// head probes + row walk per 64 of them.  Results are folded into per-wave found words in LDS and written back whole, so
+// the bitmaps keep their single-writer property.
+__device__ __forceinline__ int NthSetBit(unsigned long long x, int r)  // position of the r-th (0-based) set bit; r < popc(x)
+{
+    int pos = 0;
+#pragma unroll
+    for (int s = 32; s; s >>= 1) {
+        const int c = __popcll(x & (((1ull << s) - 1ull) << pos));
+        if (r >= c) {
+            r -= c;
+            pos += s;
+        }
+    }
+    return pos;
+}
+
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
+__global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    constexpr int WAVES = THREADS / util::kWaveSize;
+    constexpr int CHUNK_WORDS = 16;
+    __shared__ unsigned long long s_total[WAVES];
+    __shared__ unsigned s_found[WAVES][CHUNK_WORDS * 2];  // found bits of the wave's current chunk, 32-bit halves
+
+    const int tid = threadIdx.x;
+    const unsigned lane = util::LaneId();
+    const unsigned wave = tid / util::kWaveSize;
+    if (blockIdx.x == 0 && tid == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
+
+    const long long words = (static_cast<long long>(a.nodes) + 63) / 64;
+    const long long chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
+    const long long wave0 = (static_cast<long long>(blockIdx.x) * THREADS + tid) / util::kWaveSize;
+    const long long nwaves = static_cast<long long>(gridDim.x) * WAVES;
+    const VertexId new_label = slice.iteration + 1;
+    unsigned found_count = 0;
+
+    for (long long chunk = wave0; chunk < chunks; chunk += nwaves) {
+        const long long my_word = chunk * CHUNK_WORDS + lane;
+        const bool owns_word = lane < CHUNK_WORDS && my_word < words;
+        unsigned long long my_vis = ~0ull;
+        if (owns_word) my_vis = a.d_visited[my_word];
+        unsigned long long my_open = ~my_vis;
+        if (owns_word && (my_word + 1) * 64 > a.nodes) {
+            const int valid = static_cast<int>(a.nodes - my_word * 64);
+            my_open &= (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
+        }
+        const unsigned cnt = static_cast<unsigned>(__popcll(my_open));  // 0 on lanes that own no word
+        const unsigned inc = util::WaveInclusiveSum(cnt);
+        const unsigned total = __shfl(inc, CHUNK_WORDS - 1, util::kWaveSize);
+        if (total == 0) {  // wave-uniform
+            if (owns_word) a.d_frontier_out[my_word] = 0ull;
+            continue;
+        }
+        // compacted heads (see BottomUpArgs): per-word rank tables
+        unsigned long long my_with_edges = ~0ull;
+        unsigned my_base = 0;
+        if (a.d_head_base && owns_word) {
+            my_with_edges = ~a.d_never[my_word];
+            my_base = a.d_head_base[my_word];
+        }
+        if (lane < CHUNK_WORDS * 2) s_found[wave][lane] = 0;  // wave-private rows: the wave's own program order is enough
+        __builtin_amdgcn_wave_barrier();
+
+        for (unsigned base = 0; base < total; base += util::kWaveSize) {
+            const unsigned k = base + lane;
+            const bool active = k < total;
+            // word of the k-th unvisited vertex: number of words whose inclusive count is <= k
+            int j = 0;
+#pragma unroll
+            for (int w = 0; w < CHUNK_WORDS; ++w) j += (__shfl(inc, w, util::kWaveSize) <= k) ? 1 : 0;
+            if (!active) j = 0;
+            const unsigned before = __shfl(inc, j, util::kWaveSize) - __shfl(cnt, j, util::kWaveSize);
+            const unsigned long long open_j = __shfl(my_open, j, util::kWaveSize);
+            const int bit = active ? NthSetBit(open_j, static_cast<int>(k - before)) : 0;
+            const VertexId v = static_cast<VertexId>((chunk * CHUNK_WORDS + j) * 64 + bit);
+            // heads
+            long long head_index = v;
+            if (a.d_head_base) {
+                const unsigned long long we = __shfl(my_with_edges, j, util::kWaveSize);
+                head_index = __shfl(my_base, j, util::kWaveSize) + __popcll(we & ((1ull << bit) - 1ull));
+            }
+            const int2 head = a.d_inv_heads[active ? head_index : 0];
+            VertexId parent = -1;
+            const bool ask_x = active && head.x >= 0;
+            const bool hit_x = in_frontier(ask_x ? head.x : 0) && ask_x;
+            if (hit_x) parent = head.x;
+            const bool ask_y = ask_x && !hit_x && head.y >= 0;
+            bool more = false;
+            if (__ballot(ask_y) != 0) {
+                const bool hit_y = in_frontier(ask_y ? head.y : 0) && ask_y;
+                if (hit_y) parent = head.y;
+                more = ask_y && !hit_y;  // a full head: the row may hold more
+            }
+            if (a.heads_only) more = false;
+            if (__ballot(more) != 0) {
+                const VertexId late = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, more, v, lane);
+                if (more && late >= 0) parent = late;
+            }
+            if (parent >= 0) {
+                slice.d_labels[v] = new_label;
+                if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
+                atomicOr(&s_found[wave][2 * j + (bit >> 5)], 1u << (bit & 31));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (owns_word) {
+            const unsigned long long f = static_cast<unsigned long long>(s_found[wave][2 * lane]) |
+                                         (static_cast<unsigned long long>(s_found[wave][2 * lane + 1]) << 32);
+            a.d_frontier_out[my_word] = f;
+            if (f) a.d_visited[my_word] = my_vis | f;
+            found_count += static_cast<unsigned>(__popcll(f));
+        }
+    }
+
+    unsigned long long packed = util::PackTail(found_count, 0u);
+    packed = util::WaveSum(packed);
+    if (lane == 0) s_total[wave] = packed;
     __syncthreads();
     if (tid == 0) {
         unsigned long long sum = 0;
