@@ -184,6 +184,7 @@ class BFSEnactor : public EnactorBase {
         // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])
         bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
         bool force_bottom_up = false; // the last level ran count-only: its output exists only as a bitmap (already built)
+        bool queue_emitted = false;   // the last (compacting) bottom-up sweep also wrote its finds to queue[selector] + ring slot
         bool snapshot_valid = true;  // d_frontier_mask[1] holds "visited before the last top-down level" (Reset seeds it)
         int cur_mask = 0;
         int selector = 0;
@@ -191,6 +192,7 @@ class BFSEnactor : public EnactorBase {
         // bottom-up sweep: frontier = d_frontier_mask[in_mask], finds -> d_frontier_mask[out_mask]; heads_only = probe the
         // adjacency heads and stop
         auto launch_bottom_up = [&](int in_mask, int out_mask, int heads_only) -> hipError_t {
+            queue_emitted = false;
             oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
             bargs.nodes = problem->nodes;
             bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
@@ -213,11 +215,31 @@ class BFSEnactor : public EnactorBase {
             if (problem->sparse_sweep_div > 0 && open_estimate * problem->sparse_sweep_div <= static_cast<long long>(problem->nodes)) {
                 const long long chunks = ((static_cast<long long>(problem->nodes) + 63) / 64 + 15) / 16;
                 long long sgrid = (chunks + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
-                const long long scap = max_grid_size > 0 ? max_grid_size
-                    : util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
-                if (sgrid > scap) sgrid = scap;
                 if (sgrid < 1) sgrid = 1;
-                hipLaunchKernelGGL((oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>),
+                typedef oprtr::advance::BitmapLookup<VertexId> L;
+                // Emitting costs a flush (row extents, scan, writes) per workgroup, so only when this level will probably be the
+                // last bottom-up one: its input frontier is already within 32x of the switch-back threshold.
+                if (!heads_only && static_cast<double>(queue_length) * problem->beta < 32.0 * static_cast<double>(problem->nodes)) {
+                    // also emit the finds as queue[selector] (tail in this level's output ring slot): a switch back to
+                    // top-down then starts from it directly.  Fewer workgroups: each ends with one packed atomic on the slot.
+                    bargs.queue_out = gs->frontier_queues[selector];
+                    bargs.d_fwd_row_offsets = gs->d_row_offsets;
+                    bargs.d_queue_tail = work_progress.d_tail + ((iteration + 1) & 3);
+                    bargs.d_queue_invalid = reinterpret_cast<int *>(work_progress.AuxTail());
+                    bargs.d_overflow = work_progress.d_overflow;
+                    long long scap = max_grid_size > 0 ? max_grid_size
+                        : util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, L, true>, BU_THREADS);
+                    if (scap > cu_count * 4) scap = cu_count * 4;
+                    if (sgrid > scap) sgrid = scap;
+                    hipLaunchKernelGGL((oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, L, true>),
+                                       dim3(static_cast<unsigned>(sgrid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
+                    queue_emitted = true;
+                    return util::GRError("BottomUpSparseKernel launch failed", __FILE__, __LINE__);
+                }
+                const long long scap = max_grid_size > 0 ? max_grid_size
+                    : util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, L, false>, BU_THREADS);
+                if (sgrid > scap) sgrid = scap;
+                hipLaunchKernelGGL((oprtr::advance::BottomUpSparseKernel<BU_THREADS, 8, 32, BFSProblem, L, false>),
                                    dim3(static_cast<unsigned>(sgrid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
                 return util::GRError("BottomUpSparseKernel launch failed", __FILE__, __LINE__);
             }
@@ -330,14 +352,17 @@ class BFSEnactor : public EnactorBase {
                        static_cast<double>(queue_length) * problem->beta < static_cast<double>(problem->nodes)) {
                 // bitmap -> queue (exact forward degrees; zero out-degree vertices are dropped), written straight into
                 // this iteration's ring slot so the multi-level tail kernel can take over without a host round trip
-                unsigned long long *slot = work_progress.d_tail + (iteration & 3);
-                if ((retval = util::GRError(hipMemsetAsync(slot, 0, sizeof(unsigned long long), stream),
-                                            "BFSEnactor clear tail failed", __FILE__, __LINE__)))
-                    break;
-                hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256),
-                                   0, stream, ds->d_frontier_mask[cur_mask], problem->nodes,
-                                   gs->frontier_queues[selector], slot, work_progress.d_overflow, gs->d_row_offsets);
-                if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
+                if (!queue_emitted) {
+                    unsigned long long *slot = work_progress.d_tail + (iteration & 3);
+                    if ((retval = util::GRError(hipMemsetAsync(slot, 0, sizeof(unsigned long long), stream),
+                                                "BFSEnactor clear tail failed", __FILE__, __LINE__)))
+                        break;
+                    hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256),
+                                       0, stream, ds->d_frontier_mask[cur_mask], problem->nodes,
+                                       gs->frontier_queues[selector], slot, work_progress.d_overflow, gs->d_row_offsets);
+                    if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
+                }  // (else: the compacting sweep already wrote queue[selector] and this ring slot)
+                queue_emitted = false;
                 bottom_up = false;
                 snapshot_valid = false;
                 // The rest of the search usually only shrinks: one persistent launch takes the converted frontier (all CUs,
@@ -425,7 +450,17 @@ class BFSEnactor : public EnactorBase {
 
             ++iteration;
             if (bottom_up) {
-                if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
+                if ((retval = work_progress.GetAll(stream))) break;
+                queue_length = util::TailCount(work_progress.box->wide);  // finds of the sweep
+                queue_edges = 0;
+                if (queue_emitted) {  // the ring slot holds the emitted queue's packed tail, not a count to add
+                    if (work_progress.h_tail[util::WorkProgress::kAux] != 0) {  // a staging buffer overflowed: no usable queue
+                        queue_emitted = false;
+                        if ((retval = work_progress.ClearAux(stream))) break;
+                    }
+                } else {
+                    queue_length += util::TailCount(work_progress.h_tail[iteration & 3]);
+                }
             } else if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream)))
                 break;
             if (INSTRUMENT) InstrumentCollect(in_len, in_edges, bottom_up ? 1 : 0);

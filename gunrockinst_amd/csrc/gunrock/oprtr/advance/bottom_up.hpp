@@ -152,6 +152,14 @@ struct BottomUpArgs {
     // d_head_base[word] + (number of vertices WITH in-edges before it in its 64-vertex word).  nullptr: indexed by vertex id.
     const unsigned long long *d_never = nullptr;
     const unsigned *d_head_base = nullptr;
+    // the compacting sweep can also emit its finds as the next top-down queue (vertex, row start, degree prefix), so a
+    // switch back to top-down needs no bitmap -> queue pass: forward row offsets, the ring slot that receives the packed
+    // tail, and a flag raised when a workgroup's staging buffer overflowed (the queue is then unusable, the bitmap is not)
+    util::Frontier<VertexId, SizeT> queue_out;
+    const SizeT *d_fwd_row_offsets = nullptr;
+    unsigned long long *d_queue_tail = nullptr;
+    int *d_queue_invalid = nullptr;
+    int *d_overflow = nullptr;
     int heads_only = 0;                     // 1: probe the adjacency heads and stop (no CSR walk): a cheap first cut of a level
     unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
 };
@@ -303,7 +311,6 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     Lookup in_frontier)
 {
     typedef typename ProblemData::VertexId VertexId;
-    typedef typename ProblemData::SizeT SizeT;
     constexpr int WAVES = THREADS / util::kWaveSize;
     constexpr int STEP_WORDS = kBottomUpStepWords;  // bitmap words (x64 vertices) a wave takes per step; lanes 0..STEP_WORDS-1 own one word each
     __shared__ unsigned long long s_total[WAVES];
@@ -475,16 +482,24 @@ __device__ __forceinline__ int NthSetBit(unsigned long long x, int r)  // positi
     return pos;
 }
 
-template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup, bool EMIT_QUEUE>
 __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
     BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
     Lookup in_frontier)
 {
     typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
     constexpr int WAVES = THREADS / util::kWaveSize;
     constexpr int CHUNK_WORDS = 16;
+    constexpr int CAPACITY = 16 * THREADS;
+    typedef FrontierWriter<THREADS, EMIT_QUEUE ? CAPACITY : THREADS, VertexId, SizeT> Writer;
     __shared__ unsigned long long s_total[WAVES];
     __shared__ unsigned s_found[WAVES][CHUNK_WORDS * 2];  // found bits of the wave's current chunk, 32-bit halves
+    __shared__ typename Writer::Storage s_writer;
+    if (EMIT_QUEUE) {
+        Writer::Init(s_writer);
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x;
     const unsigned lane = util::LaneId();
@@ -565,6 +580,16 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
                 if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
                 atomicOr(&s_found[wave][2 * j + (bit >> 5)], 1u << (bit & 31));
             }
+            if (EMIT_QUEUE) {  // stage the finds for the queue (one LDS atomic per wave; past the capacity they are only counted)
+                const unsigned long long fm = __ballot(parent >= 0);
+                if (fm) {
+                    const int leader = __ffsll(static_cast<long long>(fm)) - 1;
+                    int at = 0;
+                    if (static_cast<int>(lane) == leader) at = atomicAdd(&s_writer.count, __popcll(fm));
+                    at = __shfl(at, leader, util::kWaveSize);
+                    if (parent >= 0 && at + __popcll(fm) <= CAPACITY) s_writer.buf[at + util::RankInMask(fm)] = v;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (owns_word) {
@@ -586,6 +611,15 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
         for (int i = 0; i < WAVES; ++i) sum += s_total[i];
         unsigned long long *slot = util::WideTailSlot(a.d_wide);
         if (sum) atomicAdd(slot ? slot : a.d_tail_out, sum);
+    }
+    if (EMIT_QUEUE) {
+        const int staged = Writer::Count(s_writer);  // (the barrier above ordered it after every append)
+        __syncthreads();
+        if (staged > CAPACITY) {
+            if (tid == 0) *a.d_queue_invalid = 1;
+        } else {
+            Writer::template Flush<true>(s_writer, staged, a.queue_out, a.d_queue_tail, a.d_overflow, a.d_fwd_row_offsets);
+        }
     }
 }
 
