@@ -134,7 +134,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // direction-optimizing switches, names from the reference's DOBFS driver (tests/dobfs/test_dobfs.cu:530-534)
     bool direction_optimizing = false;
     float alpha = 10.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges (measured optimum 8..14 on R-MAT)
-    float beta = 200.0f;  // bottom-up -> top-down when frontier_vertices * beta < nodes (measured flat optimum 96..1000 at scale-24;
+    float beta = 4000.0f; // bottom-up -> top-down when frontier_vertices * beta < nodes (measured at scale-24: 24..200 equal, 1000..4000 a little better;
                           // the reference's vertex rule, dobfs_enactor.cuh:569, with a later switch: sweeps of a nearly finished search are cheap)
     float lite_factor = 12.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
     // direction-optimizing: a level that would run count-only or bottom-up and has between min and max frontier edges starts
