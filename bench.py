@@ -181,7 +181,7 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob.set_inverse_graph()
     iprob.set_tuning(args.alpha, args.beta, args.lite_factor)
     iprob.set_head_pass(args.head_pass_min, args.head_pass_max)
-    names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel",
+    names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel / BottomUpSparseKernel",
              2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
              4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel"}
     by_kind = {}
