@@ -287,3 +287,29 @@ def test_head_pass_then_count_only_level_parity(min_edges, lite_factor, tail_lim
                 labels, preds = p.extract()
                 _check(g, int(src), labels, preds, p.stats())
             p.close()
+
+
+@pytest.mark.parametrize("min_edges,lite_factor,beta", [(1, 1e9, 0.0), (1, 8.0, 2.0), (0, 1e9, 50.0), (-1, -1.0, 0.0)])
+def test_directed_graph_new_level_kinds(min_edges, lite_factor, beta):
+    # directed R-MAT with an explicit in-neighbour CSR: heads ranked by IN-degree, compacted head indices, the heads-then-rest
+    # level, the compacting sweep and its emitted queue (which needs FORWARD row extents) must all use the right graph
+    import torch
+    for scale in (14, 17):
+        g = o.rmat_seeded(scale, 8 << scale, undirected=False)
+        src_of = np.repeat(np.arange(g.nodes, dtype=np.int32), np.diff(g.row_offsets))
+        inv0 = ga.HostGraph.from_coo(g.nodes, g.col_indices, src_of)
+        iro = torch.tensor(inv0.row_offsets, dtype=torch.int32, device="cuda")
+        ici = torch.tensor(inv0.col_indices, dtype=torch.int32, device="cuda")
+        outdeg = np.diff(g.row_offsets)
+        picks = [int(np.argmax(outdeg)), int(np.nonzero((outdeg > 0) & (outdeg < 3))[0][0])]
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph(iro.data_ptr(), ici.data_ptr(), 0.0, beta)
+            p.set_tuning(lite_factor=lite_factor)
+            p.set_head_pass(min_edges, 0 if min_edges >= 0 else -1)
+            for src in picks:
+                p.reset(src)
+                p.enact(src, traversal_mode=2)
+                labels, preds = p.extract()
+                _check(g, src, labels, preds, p.stats())
+            p.close()
