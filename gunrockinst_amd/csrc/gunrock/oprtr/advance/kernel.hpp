@@ -565,13 +565,12 @@ template <typename KernelPolicy, typename ProblemData, typename Functor>
 hipError_t LaunchPersistentLevels(const PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
                                   const typename ProblemData::DataSlice &slice, int cu_count, int grid_hint, hipStream_t stream)
 {
-    hipError_t retval = hipSuccess;
     int grid = util::ResidentGrid(PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>, KernelPolicy::THREADS);
     if (grid > cu_count) grid = cu_count;  // one workgroup per CU: every one of them is resident
     if (grid_hint > 0 && grid_hint < grid) grid = grid_hint;  // small levels: fewer workgroups = cheaper barrier
     if (grid < 1) grid = 1;
-    // contract: the two words are adjacent (WorkProgress slot 7), so one 8-byte memset re-arms both
-    GR_CHECK(hipMemsetAsync(args.barrier.d_counter, 0, 2 * sizeof(unsigned), stream), "PersistentLevels clear barrier failed");
+    // contract: barrier counter and timeout word (adjacent: WorkProgress slot 7) are ZERO at launch -- WorkProgress::Reset
+    // zeroes them at the start of an Enact and every read-back (PublishKernel) re-arms them after mirroring
     hipLaunchKernelGGL((PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(grid), dim3(KernelPolicy::THREADS), 0,
                        stream, args, slice);
     return util::GRError("advance::PersistentLevelsKernel launch failed", __FILE__, __LINE__);

@@ -67,11 +67,12 @@ struct HostMailbox {
 };
 
 // One wave: mirror the enactor's device words into the mailbox, fold + re-arm the wide tail, then publish `seq`.
-static __global__ void PublishKernel(const unsigned long long *d_tail, const unsigned long long *d_sums, unsigned long long *d_wide,
+static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned long long *d_sums, unsigned long long *d_wide,
                                      const int *d_overflow, HostMailbox *box, unsigned long long seq)
 {
     const unsigned lane = threadIdx.x;
     if (lane < 8) box->tail[lane] = d_tail[lane];
+    if (lane == 7) d_tail[7] = 0ull;  // slot 7 (grid-barrier counter | timeout of the persistent levels kernel) is re-armed here
     if (lane < 2) box->sums[lane] = d_sums[lane];
     unsigned long long w = 0;
     if (lane < 32) {
