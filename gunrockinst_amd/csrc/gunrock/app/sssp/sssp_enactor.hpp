@@ -70,15 +70,16 @@ class SSSPEnactor : public EnactorBase {
         // tail words: [0] advance output (candidates), [1] near frontier, [2]/[3] far pile (ping-pong)
         unsigned long long *d_tail = work_progress.d_tail;
         unsigned long long *h_tail = work_progress.h_tail;
-        auto read_tails = [&]() -> hipError_t { return work_progress.GetAll(stream); };
+        // one read-back per kernel; it also re-arms the words the NEXT kernel expects clean (advance output count, near tail,
+        // the far pile that is not in use, the far-minimum bucket) instead of a hipMemsetAsync per word
+        int far_selector = 0;  // far pile ping-pong: pile lives in d_far_*[far_selector], tail word 2 + far_selector
+        auto read_tails = [&]() -> hipError_t {
+            return work_progress.Sync(stream, 0x3u | (1u << (2 + (far_selector ^ 1))), 1u << 5);
+        };
         unsigned *d_far_min = reinterpret_cast<unsigned *>(d_tail + 5);
         unsigned *h_far_min = reinterpret_cast<unsigned *>(h_tail + 5);
         auto arm_far_min = [&]() -> hipError_t {
             return util::GRError(hipMemsetAsync(d_far_min, 0xFF, sizeof(unsigned), stream), "SSSPEnactor arm far-min failed",
-                                 __FILE__, __LINE__);
-        };
-        auto clear_tail = [&](int i) -> hipError_t {
-            return util::GRError(hipMemsetAsync(d_tail + i, 0, sizeof(unsigned long long), stream), "SSSPEnactor clear tail failed",
                                  __FILE__, __LINE__);
         };
 
@@ -88,8 +89,8 @@ class SSSPEnactor : public EnactorBase {
         unsigned far_min_bucket = 0xFFFFFFFFu;  // smallest bucket currently parked (lower bound)
         unsigned level = 0;
         int selector = 0;      // frontier ping-pong
-        int far_selector = 0;  // far pile ping-pong: pile lives in d_far_*[far_selector], tail word 2 + far_selector
         int tag = 0;
+        if ((retval = arm_far_min())) return retval;  // (the first read-back re-arms from then on)
         const int grid = enactor_stats.advance_grid_size;
 
         while (queue_length > 0 || far_length > 0) {
@@ -98,7 +99,6 @@ class SSSPEnactor : public EnactorBase {
                 relaxed_edges += queue_edges;
                 enactor_stats.total_queued += queue_length;
                 // ---- advance: relax every out-edge of the frontier; improved destinations -> candidates ----
-                if ((retval = clear_tail(0))) break;
                 oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
                 args.in = gs->frontier_queues[selector];
                 args.out = util::Frontier<VertexId, SizeT>();
@@ -124,8 +124,6 @@ class SSSPEnactor : public EnactorBase {
                 queue_length = 0;
                 queue_edges = 0;
                 if (candidates > 0) {
-                    if ((retval = clear_tail(1))) break;
-                    if ((retval = arm_far_min())) break;
                     priority_queue::BisectArgs<VertexId, SizeT> b;
                     b.d_far_min = d_far_min;
                     b.d_in = problem->d_candidates;
@@ -159,9 +157,6 @@ class SSSPEnactor : public EnactorBase {
                 // next level; skip levels no parked vertex can be in
                 ++level;
                 if (far_min_bucket != 0xFFFFFFFFu && far_min_bucket > level) level = far_min_bucket;
-                if ((retval = clear_tail(1))) break;
-                if ((retval = clear_tail(2 + (far_selector ^ 1)))) break;
-                if ((retval = arm_far_min())) break;
                 priority_queue::BisectArgs<VertexId, SizeT> b;
                 b.d_far_min = d_far_min;
                 b.d_in = problem->d_far_v[far_selector];
@@ -180,9 +175,9 @@ class SSSPEnactor : public EnactorBase {
                 if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
                 if ((retval = priority_queue::Bisect<256, 4, SSSPProblem, PqFunctor>(b, *ds, grid, stream))) break;
                 if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
+                far_selector ^= 1;  // (before the read-back: it clears the tail of the pile that is out of use from now on)
                 if ((retval = read_tails())) break;
                 if (INSTRUMENT) InstrumentCollect(far_length, 0, 2);
-                far_selector ^= 1;
                 queue_length = util::TailCount(h_tail[1]);
                 queue_edges = util::TailEdges(h_tail[1]);
                 far_length = util::TailCount(h_tail[2 + far_selector]);

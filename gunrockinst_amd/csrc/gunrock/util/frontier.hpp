@@ -68,11 +68,18 @@ struct HostMailbox {
 
 // One wave: mirror the enactor's device words into the mailbox, fold + re-arm the wide tail, then publish `seq`.
 static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned long long *d_sums, unsigned long long *d_wide,
-                                     const int *d_overflow, HostMailbox *box, unsigned long long seq)
+                                     const int *d_overflow, HostMailbox *box, unsigned long long seq, unsigned clear_mask,
+                                     unsigned ones_mask)
 {
+    // clear_mask / ones_mask: slots to zero / to set their low word to 0xFFFFFFFF AFTER mirroring -- the re-arming an enactor
+    // would otherwise do with one hipMemsetAsync per word before its next kernel
     const unsigned lane = threadIdx.x;
-    if (lane < 8) box->tail[lane] = d_tail[lane];
-    if (lane == 7) d_tail[7] = 0ull;  // slot 7 (grid-barrier counter | timeout of the persistent levels kernel) is re-armed here
+    if (lane < 8) {
+        const unsigned long long v = d_tail[lane];
+        box->tail[lane] = v;
+        if (lane == 7 || ((clear_mask >> lane) & 1u)) d_tail[lane] = 0ull;  // slot 7: grid barrier of the persistent levels kernel
+        else if ((ones_mask >> lane) & 1u) d_tail[lane] = v | 0xFFFFFFFFull;
+    }
     if (lane < 2) box->sums[lane] = d_sums[lane];
     unsigned long long w = 0;
     if (lane < 32) {
@@ -147,11 +154,12 @@ struct WorkProgress {
     }
 
     // Mirror all device words into the mailbox and wait for them (the only host<->device sync of a BSP step).
-    hipError_t Sync(hipStream_t stream)
+    hipError_t Sync(hipStream_t stream, unsigned clear_mask = 0, unsigned ones_mask = 0)
     {
         hipError_t retval = hipSuccess;
         ++seq;
-        hipLaunchKernelGGL(PublishKernel, dim3(1), dim3(64), 0, stream, d_tail, d_sums, d_wide, d_overflow, box, seq);
+        hipLaunchKernelGGL(PublishKernel, dim3(1), dim3(64), 0, stream, d_tail, d_sums, d_wide, d_overflow, box, seq, clear_mask,
+                           ones_mask);
         GR_CHECK(hipGetLastError(), "WorkProgress PublishKernel launch failed");
         volatile unsigned long long *flag = &box->seq;
         unsigned spins = 0;
