@@ -71,7 +71,7 @@ class CCEnactor : public EnactorBase {
 #define GR_CC_SWEEP(Functor, count, kind)                                                                            \
     do {                                                                                                             \
         if (INSTRUMENT && (retval = InstrumentBegin(stream))) return retval;                                         \
-        if ((retval = oprtr::filter::LaunchApply<FilterPolicy, CCProblem, Functor>(nullptr, (count), nullptr, *ds,  \
+        if ((retval = oprtr::filter::LaunchApply<FilterPolicy, CCProblem, Functor>(nullptr, (count), nullptr, slice, \
                                                                                     grid, stream)))                 \
             return retval;                                                                                           \
         if (INSTRUMENT) {                                                                                            \
@@ -83,40 +83,40 @@ class CCEnactor : public EnactorBase {
         enactor_stats.total_queued += (count);                                                                       \
     } while (0)
 
-        // flags: set both to 1, run the sweep, read them back (one 8-byte copy)
-        auto arm = [&]() -> hipError_t {
-            problem->h_flags[0] = problem->h_flags[1] = 1;
-            return util::GRError(hipMemcpyAsync(ds->d_vertex_flag, problem->h_flags, sizeof(int) * 2, hipMemcpyHostToDevice, stream),
-                                 "CCEnactor arm flags failed", __FILE__, __LINE__);
-        };
+        // Convergence flags: the two ints of WorkProgress slot 0 (vertex flag low, edge flag high).  A sweep that changes
+        // something clears its flag; poll() is the read-back kernel, which mirrors the word to pinned memory and sets it back
+        // to all ones for the next sweep -- no copy up, no copy down, no stream synchronisation per sweep.
+        typename CCProblem::DataSlice slice = *ds;
+        slice.d_vertex_flag = reinterpret_cast<int *>(work_progress.d_tail);
+        slice.d_edge_flag = slice.d_vertex_flag + 1;
+        if ((retval = work_progress.Reset(stream))) return retval;
+        GR_CHECK(hipMemsetAsync(work_progress.d_tail, 0xFF, sizeof(unsigned long long), stream), "CCEnactor arm flags failed");
+        bool vertex_stable = false, edge_stable = false;
         auto poll = [&]() -> hipError_t {
-            hipError_t rc = util::GRError(hipMemcpyAsync(problem->h_flags, ds->d_vertex_flag, sizeof(int) * 2, hipMemcpyDeviceToHost, stream),
-                                          "CCEnactor read flags failed", __FILE__, __LINE__);
-            if (rc) return rc;
-            return util::GRError(hipStreamSynchronize(stream), "CCEnactor sync failed", __FILE__, __LINE__);
+            hipError_t rc = work_progress.Sync(stream, 0u, 1u);
+            vertex_stable = (work_progress.h_tail[0] & 0xFFFFFFFFull) != 0;
+            edge_stable = (work_progress.h_tail[0] >> 32) != 0;
+            return rc;
         };
 
         if (m > 0) GR_CC_SWEEP(HookInit, m, 1);
         for (;;) {  // first pointer-jumping round (cc_enactor.cuh:442-493)
-            if ((retval = arm())) return retval;
             GR_CC_SWEEP(PtrJump, n, 0);
             if ((retval = poll())) return retval;
             ++enactor_stats.iteration;
-            if (problem->h_flags[0]) break;
+            if (vertex_stable) break;
         }
         GR_CC_SWEEP(UpdateMask, n, 0);
 
         while (m > 0) {  // cc_enactor.cuh:524-862
-            if ((retval = arm())) return retval;
             GR_CC_SWEEP(HookMax, m, 1);
             if ((retval = poll())) return retval;
             ++enactor_stats.iteration;
-            if (problem->h_flags[1]) break;  // no edge hooked anything: done
+            if (edge_stable) break;  // no edge hooked anything: done
             for (;;) {
-                if ((retval = arm())) return retval;
                 GR_CC_SWEEP(PtrJumpMask, n, 0);
                 if ((retval = poll())) return retval;
-                if (problem->h_flags[0]) break;
+                if (vertex_stable) break;
             }
             GR_CC_SWEEP(PtrJumpUnmask, n, 0);
             GR_CC_SWEEP(UpdateMask, n, 0);

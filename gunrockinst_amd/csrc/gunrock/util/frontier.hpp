@@ -71,14 +71,14 @@ static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned 
                                      const int *d_overflow, HostMailbox *box, unsigned long long seq, unsigned clear_mask,
                                      unsigned ones_mask)
 {
-    // clear_mask / ones_mask: slots to zero / to set their low word to 0xFFFFFFFF AFTER mirroring -- the re-arming an enactor
+    // clear_mask / ones_mask: slots to zero / to set to all ones AFTER mirroring -- the re-arming an enactor
     // would otherwise do with one hipMemsetAsync per word before its next kernel
     const unsigned lane = threadIdx.x;
     if (lane < 8) {
         const unsigned long long v = d_tail[lane];
         box->tail[lane] = v;
         if (lane == 7 || ((clear_mask >> lane) & 1u)) d_tail[lane] = 0ull;  // slot 7: grid barrier of the persistent levels kernel
-        else if ((ones_mask >> lane) & 1u) d_tail[lane] = v | 0xFFFFFFFFull;
+        else if ((ones_mask >> lane) & 1u) d_tail[lane] = ~0ull;
     }
     if (lane < 2) box->sums[lane] = d_sums[lane];
     unsigned long long w = 0;
