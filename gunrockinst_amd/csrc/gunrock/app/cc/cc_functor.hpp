@@ -67,8 +67,15 @@ struct HookMaxFunctor {
     static __device__ __forceinline__ void ApplyFilter(VertexId edge, DataSlice *problem, Value = 0, SizeT = 0)
     {
         if (problem->d_marks[edge]) return;
-        const VertexId pf = LoadFresh(problem->d_component_ids + problem->d_froms[edge]);
-        const VertexId pt = LoadFresh(problem->d_component_ids + problem->d_tos[edge]);
+        const VertexId f = problem->d_froms[edge], t = problem->d_tos[edge];
+        // mirrored input (CCProblem checked it): the edge (t, f) does this very hook, so one orientation is enough; park the
+        // other one for good
+        if (problem->symmetric && f < t) {
+            problem->d_marks[edge] = 1;
+            return;
+        }
+        const VertexId pf = LoadFresh(problem->d_component_ids + f);
+        const VertexId pt = LoadFresh(problem->d_component_ids + t);
         if (pf == pt) {
             problem->d_marks[edge] = 1;
         } else {

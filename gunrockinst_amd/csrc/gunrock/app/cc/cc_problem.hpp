@@ -49,6 +49,28 @@ __global__ void ExpandRowsKernel(const SizeT *d_row_offsets, SizeT nodes, Vertex
     }
 }
 
+// Does every edge (f, t) with f < t have its mirror (t, f)?  One lane per such edge, binary search of f in row t (rows sorted
+// ascending, as Csr::FromCoo builds them; an unsorted row can only produce a false "no", which is the safe answer).  That is
+// all the hooking sweeps need to skip the f < t orientation: the mirror, an edge with from > to, is always processed.
+template <typename VertexId, typename SizeT>
+__global__ void MirrorCheckKernel(const SizeT *d_row_offsets, const VertexId *d_froms, const VertexId *d_tos, long long edges,
+                                  int *d_missing)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    bool missing = false;
+    for (long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < edges; e += stride) {
+        const VertexId f = d_froms[e], t = d_tos[e];
+        if (f >= t) continue;
+        SizeT lo = d_row_offsets[t], hi = d_row_offsets[t + 1];
+        while (lo < hi) {
+            const SizeT mid = lo + (hi - lo) / 2;
+            if (d_tos[mid] < f) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= d_row_offsets[t + 1] || d_tos[lo] != f) missing = true;
+    }
+    if (__ballot(missing) && util::LaneId() == 0) *d_missing = 1;
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _USE_DOUBLE_BUFFER>
 struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     typedef ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> Base;
@@ -64,6 +86,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         unsigned char *d_marks = nullptr;     // per edge: both ends already in one tree
         VertexId *d_froms = nullptr;          // per edge: source vertex
         const VertexId *d_tos = nullptr;      // per edge: destination vertex (= CSR column_indices)
+        int symmetric = 0;                    // every edge has its mirror: hooking sweeps need one orientation only
         int *d_vertex_flag = nullptr;         // cleared by a pointer-jump sweep that changed something
         int *d_edge_flag = nullptr;           // cleared by a hook sweep that hooked something
     };
@@ -111,6 +134,19 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                                this->nodes, ds->d_froms);
             GR_CHECK(hipGetLastError(), "ExpandRowsKernel launch failed");
             GR_CHECK(hipStreamSynchronize(gs->stream), "ExpandRowsKernel failed");
+        }
+        // Mirrored input (what the reference's CC drivers build, test_cc.cu "undirected")?  Then (f, t) with f < t and its
+        // mirror are the same hook, and the hooking sweeps skip the f < t orientation.  Checked once here, outside Enact.
+        ds->symmetric = 0;
+        if (this->edges > 0) {
+            GR_CHECK(hipMemsetAsync(ds->d_vertex_flag, 0, sizeof(int) * 2, gs->stream), "CCProblem memset failed");
+            hipLaunchKernelGGL((MirrorCheckKernel<VertexId, SizeT>), dim3(4096), dim3(256), 0, gs->stream, gs->d_row_offsets, ds->d_froms,
+                               ds->d_tos, static_cast<long long>(this->edges), ds->d_vertex_flag);
+            GR_CHECK(hipGetLastError(), "MirrorCheckKernel launch failed");
+            int missing = 0;
+            GR_CHECK(hipMemcpyAsync(&missing, ds->d_vertex_flag, sizeof(int), hipMemcpyDeviceToHost, gs->stream), "CCProblem read failed");
+            GR_CHECK(hipStreamSynchronize(gs->stream), "MirrorCheckKernel failed");
+            ds->symmetric = missing ? 0 : 1;
         }
         return retval;
     }
