@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6772)
     ap.add_argument("--cpu-baseline-runs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--primitive", choices=["bfs", "cc", "sssp"], default="bfs",
+    ap.add_argument("--primitive", choices=["bfs", "cc", "sssp", "bc"], default="bfs",
                     help="bfs = the headline metric (default); cc / sssp = BASELINE.json configs 4 / 3 on one GPU")
     ap.add_argument("--delta-factor", type=int, default=16)
     ap.add_argument("--skip-topdown-leg", action="store_true",
@@ -88,6 +88,8 @@ def main():
         result = bench_cc(args, torch, ga, devgraph, local_rank)
     elif args.primitive == "sssp":
         result = bench_sssp(args, torch, ga, devgraph, local_rank)
+    elif args.primitive == "bc":
+        result = bench_bc(args, torch, ga, devgraph, local_rank)
     else:
         result = bench_single(args, torch, ga, devgraph, local_rank)
     if rank == 0:
@@ -272,6 +274,64 @@ def bench_single(args, torch, ga, devgraph, device_index):
         "parity_vs_oracle": parity,
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_parallel,
     }
+
+
+def bench_bc(args, torch, ga, devgraph, device_index):
+    """Betweenness centrality: one Brandes pass per step (forward BFS with path counts + backward
+    dependency accumulation) from the largest-degree source and seeded sources, R-MAT as for the other primitives."""
+    import numpy as np
+    n = 1 << args.scale
+    ro, ci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+    m = int(ci.shape[0])
+    deg = (ro[1:] - ro[:-1]).long()
+    src0, _ = devgraph.largest_degree_source(ro)
+    sources = [src0] + devgraph.seeded_sources(ro, 8, args.seed)
+    p = ga.BcProblem(device_index).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    steps = max(1, min(args.steps, len(sources)))
+    for k in range(min(args.warmup, 2)):
+        p.run(sources[k % len(sources)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_ms = 0.0
+    for k in range(steps):
+        run_ms += p.run(sources[k % len(sources)])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    # edges of the reached component, from a BFS of the same source (every reached vertex's edges are walked twice)
+    bp = ga.BfsProblem(False, True, False, device_index).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    edges_total, nodes_total = 0, 0
+    for k in range(steps):
+        s = sources[k % len(sources)]
+        bp.reset(s); bp.enact(s, traversal_mode=0)
+        vis = devgraph.as_tensor(bp.device_results()[0], n) > -1
+        nodes_total += int(vis.sum()); edges_total += int(deg[vis].sum())
+    bp.close()
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        from oracle import gr_oracle as o
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        g = o.Csr(n, h_ro, h_ci)
+        t0 = time.perf_counter()
+        ref, _ = o.bc(g, src0)
+        cpu_s = time.perf_counter() - t0
+        p.run(src0)
+        _, got = p.extract()
+        parity = bool(np.all(np.abs(got.astype(np.float64) - ref) <= 1e-3 * np.abs(ref) + 1e-3))
+        cpu = {"value": round(edges_total / steps * 2 / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+               "sample": "1 Brandes pass (oracle, doubles) from the max-degree source, %.1f s" % cpu_s}
+    p.close()
+    balg = 8.0 * edges_total + 40.0 * nodes_total   # forward + backward: 4 B per edge each way, ~40 B of per-vertex state
+    achieved = balg / (run_ms * 1e-3) / 1e9
+    return {"metric": "BC R-MAT scale-%d: MTEPS = 2 x edges of reached vertices / time of one source (forward + backward)" % args.scale,
+            "value": round(2.0 * edges_total / (run_ms * 1e3), 2), "unit": "MTEPS", "n_gpus": 1, "steps": steps,
+            "warmup": min(args.warmup, 2), "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BC (Brandes, one source per step), R-MAT scale-%d: n=%d, m=%d" % (args.scale, n, m)},
+            "run_ms_per_step": round(run_ms / steps, 4), "parity_vs_oracle": parity,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": "advance::LoadBalancedKernel<Forward/BackwardFunctor>",
+                         "alg_bytes": balg, "note": "whole Reset + Enact device time of a source (grx_bc_run)"},
+            "cpu_baseline": cpu}
 
 
 def bench_cc(args, torch, ga, devgraph, device_index):

@@ -126,6 +126,10 @@ class BCEnactor : public EnactorBase {
                                                                                                         oprtr::advance::V2V)))
                 return retval;
         }
+        // dependencies are final: fold them into the running centralities, once per vertex
+        hipLaunchKernelGGL((AccumulateKernel<Value>), dim3(util::MemsetGrid(problem->nodes)), dim3(256), 0, stream, ds->d_bc_values,
+                           ds->d_deltas, static_cast<long long>(problem->nodes));
+        if ((retval = util::GRError("AccumulateKernel launch failed", __FILE__, __LINE__))) return retval;
         return util::GRError(hipStreamSynchronize(stream), "BCEnactor sync failed", __FILE__, __LINE__);
     }
 

@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <gunrock/util/device_intrinsics.hpp>
+
 namespace gunrock {
 namespace app {
 namespace bc {
@@ -20,6 +22,15 @@ namespace bc {
 template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
 struct ForwardFunctor {
     typedef typename ProblemData::DataSlice DataSlice;
+
+    // side-effect-free screen (optional advance hook): a destination labelled on an EARLIER level takes no part -- no
+    // memory-side atomic for it (most edges of the big levels)
+    static __device__ __forceinline__ bool ScreenEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
+                                                      VertexId /*e_id_in*/ = 0)
+    {
+        const VertexId label = problem->d_labels[d_id];  // (a stale -1 only costs the atomicCAS below)
+        return label == -1 || label == problem->iteration + 1;
+    }
 
     static __device__ __forceinline__ bool CondEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
                                                     VertexId /*e_id_in*/ = 0)
@@ -52,11 +63,38 @@ struct BackwardFunctor {
     static __device__ __forceinline__ void ApplyEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
                                                      VertexId /*e_id_in*/ = 0)
     {
+        // the reference adds the same amount to bc_values[s] here (bc_functor.cuh:205-208); deltas are final once the backward
+        // phase is over, so bc_values += deltas runs once per vertex afterwards (BCEnactor) instead of once per edge
         const Value result = problem->d_sigmas[s_id] / problem->d_sigmas[d_id] * (static_cast<Value>(1) + problem->d_deltas[d_id]);
-        if (s_id != problem->src_node) {
-            atomicAdd(problem->d_deltas + s_id, result);
-            atomicAdd(problem->d_bc_values + s_id, result);
+        if (s_id != problem->src_node) atomicAdd(problem->d_deltas + s_id, result);
+    }
+    // Wave form of ApplyEdge (advance hook, oprtr/advance/kernel.hpp): consecutive lanes hold consecutive edge slots, so the
+    // edges of one source form runs of lanes.  A segmented sum over each run (6 shuffle steps) leaves the run's total in
+    // its last lane, which issues the ONE atomicAdd -- a hub with 2e5 edges was 2e5 atomics on one address (they retire at
+    // ~80 per microsecond), now ~3e3.
+    static __device__ __forceinline__ void ApplyEdgeWave(VertexId s_id, VertexId d_id, bool live, DataSlice *problem, VertexId /*e_id*/ = 0,
+                                                         VertexId /*e_id_in*/ = 0)
+    {
+        const unsigned lane = util::LaneId();
+        live = live && s_id != problem->src_node;
+        Value val = 0;
+        if (live) val = problem->d_sigmas[s_id] / problem->d_sigmas[d_id] * (static_cast<Value>(1) + problem->d_deltas[d_id]);
+        // run = maximal stretch of consecutive lanes with the same live source (an edge of the row that failed CondEdge ends a
+        // run: its lane is "dead").  Run ids count the stretch starts up to the lane, so equal ids <=> same contiguous stretch.
+        const int key = live ? static_cast<int>(s_id) : -1;
+        const int prev_key = __shfl_up(key, 1, util::kWaveSize);
+        const bool starts = lane == 0 || prev_key != key || !live;
+        const unsigned long long start_mask = __ballot(starts);
+        const int run = __popcll(start_mask & ((2ull << lane) - 1ull));  // stretch starts at or before this lane
+#pragma unroll
+        for (int o = 1; o < util::kWaveSize; o <<= 1) {
+            const int other_run = __shfl_up(run, o, util::kWaveSize);
+            const Value other_val = __shfl_up(val, o, util::kWaveSize);
+            if (static_cast<int>(lane) >= o && other_run == run) val += other_val;
         }
+        const int next_run = __shfl_down(run, 1, util::kWaveSize);
+        const bool run_end = lane == util::kWaveSize - 1 || next_run != run;
+        if (live && run_end) atomicAdd(problem->d_deltas + s_id, val);
     }
     static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice * /*problem*/, Value /*v*/ = 0, SizeT /*nid*/ = 0)
     {

@@ -27,6 +27,14 @@ __global__ void ScaleKernel(Value *d_out, Value factor, long long length)
     for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < length; i += stride) d_out[i] *= factor;
 }
 
+// bc_values[v] += deltas[v] (the source's delta is never accumulated, so it adds 0)
+template <typename Value>
+__global__ void AccumulateKernel(Value *d_bc, const Value *d_deltas, long long length)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < length; i += stride) d_bc[i] += d_deltas[i];
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _MARK_PREDECESSORS, bool _USE_DOUBLE_BUFFER>
 struct BCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     typedef ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> Base;

@@ -66,6 +66,16 @@ __device__ __forceinline__ bool ScreenEdge(VertexId s, VertexId d, DataSlice *sl
     else return true;
 }
 
+// Optional functor hook `ApplyEdgeWave(s_id, d_id, live, problem, e_id, e_id_in)`: called INSTEAD of ApplyEdge, by every lane
+// of the wave (live = this lane's edge passed CondEdge), so the functor may combine lanes -- consecutive lanes hold consecutive
+// edge slots, i.e. runs of the same source -- before it touches memory (BC's dependency sums: one atomic per run, not per edge).
+template <typename Functor, typename VertexId, typename DataSlice, typename = void>
+struct HasApplyEdgeWave : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice>
+struct HasApplyEdgeWave<Functor, VertexId, DataSlice,
+                        std::void_t<decltype(Functor::ApplyEdgeWave(VertexId(), VertexId(), false, static_cast<DataSlice *>(nullptr),
+                                                                    VertexId(), VertexId()))>> : std::true_type {};
+
 template <typename VertexId, typename SizeT>
 struct AdvanceArgs {
     util::Frontier<VertexId, SizeT> in;
@@ -247,11 +257,19 @@ __device__ __forceinline__ void ExpandTiles(
         for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
             live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
         int mine = 0;
+        if constexpr (HasApplyEdgeWave<Functor, VertexId, typename ProblemData::DataSlice>::value) {
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            if (live[k]) {
-                Functor::ApplyEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
-                ++mine;
+            for (int k = 0; k < ITEMS; ++k) {  // every lane calls: the functor works across the wave
+                Functor::ApplyEdgeWave(src[k], dst[k], live[k], &slice, edge[k], slot0 + k * THREADS + tid);
+                mine += live[k] ? 1 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                if (live[k]) {
+                    Functor::ApplyEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
+                    ++mine;
+                }
             }
         }
         accepted += static_cast<unsigned>(mine);
