@@ -1,15 +1,16 @@
 /*
- * gr_oracle.h -- CPU oracle for the BFS / CC / SSSP frontier path.
+ * gr_oracle.h -- CPU oracle for the BFS / CC / SSSP (+ BC) frontier path.
  *
  * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
  * host-side algorithms (graph ingest, R-MAT generator, CPU reference BFS,
- * Dijkstra, connected components).  Only tests/, __graft_entry__.smoke() and
+ * Dijkstra, connected components, Brandes betweenness centrality), plus an
+ * OpenMP BFS that exists only as the all-cores CPU baseline of bench.py.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load it; the product library
  * (gunrockinst_amd/csrc -> libgunrock.so) never links or calls it.
  *
  * Pinning (see DESIGN.md "Oracle"): checked against the reference's own
  * fixtures -- shared_lib_tests/test_bfs.c:32-33 (CSR of dataset/small/test_bc.mtx),
- * CMakeLists.txt:215-229 (known-answer regexes), dataset/small/test_cc.mtx,
+ * CMakeLists.txt:215-229 (known-answer regexes, BC's 0.500000 included), dataset/small/test_cc.mtx,
  * simple_example/bips98_606.mtx -- and against the golden values the survey
  * captured from the reference's host code, committed
  * under tests/golden/reference_goldens.json.
