@@ -56,6 +56,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Libraries write banners to stdout (RCCL prints its version block when the first communicator is created): everything
+    # but the result line goes to stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,7 +99,9 @@ def main():
     else:
         result = bench_single(args, torch, ga, devgraph, local_rank)
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)  # the real stdout carries exactly one line
+        print(json.dumps(result), flush=True)
     if partitioned:
         dist.barrier()
         dist.destroy_process_group()
