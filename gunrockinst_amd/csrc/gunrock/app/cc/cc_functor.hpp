@@ -106,7 +106,22 @@ struct HookMinFunctor {
     }
 };
 
-// parent[v] = parent[parent[v]]      -- cc_functor.cuh:230-262
+// Pointer jumping follows up to kJumpHops parents per sweep instead of the reference's one (parent[v] = parent[parent[v]],
+// cc_functor.cuh:230-262): every value read on the way is an ancestor of v (ids only ever decrease towards the root), so the
+// fixed point -- every vertex points at its root -- is the same; a round of sweeps converges in 2-3 launches instead of 5-7.
+constexpr int kJumpHops = 8;
+template <typename VertexId, typename DataSlice>
+__device__ __forceinline__ VertexId JumpFrom(VertexId parent, DataSlice *problem)
+{
+#pragma unroll 1
+    for (int hop = 0; hop < kJumpHops; ++hop) {
+        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        if (grand == parent) break;
+        parent = grand;
+    }
+    return parent;
+}
+
 template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
 struct PtrJumpFunctor {
     typedef typename ProblemData::DataSlice DataSlice;
@@ -114,7 +129,7 @@ struct PtrJumpFunctor {
     static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
     {
         const VertexId parent = LoadFresh(problem->d_component_ids + node);
-        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        const VertexId grand = JumpFrom(parent, problem);
         if (parent != grand) {
             StoreFresh(problem->d_vertex_flag, 0);
             StoreFresh(problem->d_component_ids + node, grand);
@@ -131,7 +146,7 @@ struct PtrJumpMaskFunctor {
     {
         if (problem->d_masks[node] != 0) return;
         const VertexId parent = LoadFresh(problem->d_component_ids + node);
-        const VertexId grand = LoadFresh(problem->d_component_ids + parent);
+        const VertexId grand = JumpFrom(parent, problem);
         if (parent != grand) {
             StoreFresh(problem->d_vertex_flag, 0);
             StoreFresh(problem->d_component_ids + node, grand);
