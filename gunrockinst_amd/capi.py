@@ -96,6 +96,7 @@ _SIGNATURES = {
     "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
+    "grx_bfs_set_binned_min_edges": (C.c_int, [C.c_void_p, C.c_longlong]),
     "grx_bfs_set_head_pass": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -298,6 +299,10 @@ class BfsProblem:
 
     def set_head_pass(self, min_edges=-1, max_edges=-1):
         _check(lib().grx_bfs_set_head_pass(self._h, int(min_edges), int(max_edges)), "grx_bfs_set_head_pass")
+        return self
+
+    def set_binned_min_edges(self, min_edges):
+        _check(lib().grx_bfs_set_binned_min_edges(self._h, int(min_edges)), "grx_bfs_set_binned_min_edges")
         return self
 
     def set_persistent_limit(self, edge_limit):

@@ -57,7 +57,10 @@ class BFSEnactor : public EnactorBase {
 
     // Load-balanced advance policy: 256 threads x 8 slots = 2048 edge slots per tile, 37 KB LDS,
     // 4 workgroups (16 waves) per CU.
-    typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> LBAdvancePolicy;
+#ifndef GRX_LB_ITEMS
+#define GRX_LB_ITEMS 4
+#endif
+    typedef oprtr::advance::KernelPolicy<256, GRX_LB_ITEMS, 8, oprtr::advance::LB> LBAdvancePolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
     // Persistent mid-size levels: 1024-thread workgroups (one edge slot per thread: the level is latency-bound, so spread it
@@ -441,7 +444,31 @@ class BFSEnactor : public EnactorBase {
                     if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 4);
                     continue;  // (selector unchanged: no queue was written)
                 }
-                if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
+                if (problem->binned_min_edges > 0 && static_cast<long long>(queue_edges) >= problem->binned_min_edges) {
+                    // ---- destination-binned level (oprtr/advance/binned.hpp): no claim atomics ----
+                    int expand_grid = util::ResidentGrid(oprtr::advance::BinnedExpandKernel<AdvancePolicy, BFSProblem, BfsFunctor>,
+                                                         AdvancePolicy::THREADS);
+                    if (max_grid_size > 0) expand_grid = max_grid_size;
+                    const int apply_grid = util::ResidentGrid(
+                        oprtr::advance::BinnedApplyKernel<256, BFSProblem, BfsFunctor, BFSProblem::MARK_PREDECESSORS>, 256);
+                    if ((retval = problem->EnsureBinned(expand_grid, work_progress.d_overflow))) break;
+                    ds = problem->data_slices[0];
+                    if ((retval = problem->bin_pool.Arm(stream))) break;
+                    args.bins = problem->bin_pool.view;
+                    typename BFSProblem::DataSlice expand_slice = *ds, apply_slice = *ds;
+                    expand_slice.lite = 3;  // phase 1: screen against the visited bitmap (constant during the level)
+                    apply_slice.lite = 2;   // phase 2: screen + claim on the destination's flag byte, on its owner XCD
+                    retval = oprtr::advance::LaunchBinned<AdvancePolicy, BFSProblem, BfsFunctor>(args, expand_slice, apply_slice,
+                                                                                               expand_grid, apply_grid, stream);
+                    if (retval) break;
+                    // closing sweep: flag bytes -> labels (vertex order), visited bitmap, this level's discoveries as a bitmap ...
+                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask), nullptr))) break;
+                    // ... and as the next queue (vertex order, exact degrees), its packed tail in this level's output ring slot
+                    hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
+                                       stream, ds->d_frontier_mask[0], problem->nodes, gs->frontier_queues[selector ^ 1],
+                                       work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_overflow, gs->d_row_offsets);
+                    if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
+                } else if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
                          args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;
                 selector ^= 1;

@@ -34,15 +34,22 @@ struct BFSFunctor {
         // L1-bypassing load (global_load sc1, served by the XCD's L2): a line parked in this CU's L1 is never refreshed
         // during the launch, so hot words (hubs) would keep reading "unvisited" and every edge into a hub discovered on
         // this level would pay a memory-side atomic -- measured: the heavy top-down levels were atomic-bound.
-        const unsigned word = __hip_atomic_load(problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5), __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
+        // phase 2 of a binned level (oprtr/advance/binned.hpp): this workgroup runs on the XCD that owns d_id's flag byte, so a
+        // load served by that XCD's L2 sees every earlier claim of the level
+        if (problem->lite == 2)
+            return __hip_atomic_load(problem->d_fresh + d_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        // In the other lite modes (count-only level, phase 1 of a binned level) nothing writes the bitmap while the advance runs:
+        // plain loads, so the hub lines stay in L1.
+        const unsigned *wp = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
+        const unsigned word = problem->lite ? *wp : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return (word & (1u << (d_id & 31))) == 0;        // still stale-tolerant: a miss only costs an atomic
     }
 
     static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
                                                     VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-        if (problem->lite) {
+        if (problem->lite) {  // (binned phase 2 included: ScreenEdge saw the flag clear; two claims inside one store latency
+                              //  both pass, harmlessly -- the closing sweep dedupes, every same-level source is a valid parent)
             // count-only level (oprtr/advance/bottom_up.hpp FreshToBitmapKernel): every edge into an unvisited vertex may
             // "discover" it -- all sources of one level are equally valid parents -- so a plain byte store replaces the claim
             // (A best-effort same-level filter in the bitmap -- plain byte read-modify-write, the reference's bitmask cull,

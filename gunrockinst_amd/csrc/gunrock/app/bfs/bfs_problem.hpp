@@ -21,6 +21,7 @@
 
 #include <gunrock/app/problem_base.hpp>
 #include <gunrock/graphio/device_csr.hpp>
+#include <gunrock/oprtr/advance/binned.hpp>
 #include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
@@ -154,6 +155,11 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (head_pass_max_edges == 0) return 1ll << 40;
         return static_cast<long long>(static_cast<double>(this->edges) / 7.8);
     }
+    // Top-down levels with at least this many frontier edges run as a destination-binned advance (oprtr/advance/binned.hpp):
+    // expand + screen, claims on the destination's owner XCD without atomics, then a vertex-ordered closing sweep
+    // (FreshToBitmapKernel + BitmapToQueueKernel) that labels, dedupes and enqueues.  0 = never.
+    long long binned_min_edges = 1ll << 21;
+    oprtr::advance::BinPoolStorage<VertexId> bin_pool;
     int persistent_edge_limit = 1 << 20;  // ... and up to this many inside the persistent multi-workgroup kernel (0 = off)
     int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 
@@ -181,6 +187,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             delete[] data_slices;
         }
         if (h_src_box) util::GRError(hipHostFree(h_src_box), "BFSProblem hipHostFree failed", __FILE__, __LINE__);
+        bin_pool.Release();
     }
 
     // bitmaps are sized in whole 64-bit words: one wave owns one word in the bottom-up sweep
@@ -260,6 +267,26 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         direction_optimizing = true;
         return retval;
     }
+    // Scratch of the binned advance: the chunk pool (sized for a level that hands over every edge of the graph from
+    // `workgroups` workgroups), the flag bytes and the bitmap its closing sweep writes.  Allocated on first use.
+    hipError_t EnsureBinned(int workgroups, int *d_overflow)
+    {
+        hipError_t retval = hipSuccess;
+        DataSlice *ds = data_slices[0];
+        if (!bin_pool.Ready() || bin_pool.workgroups < workgroups)
+            GR_CHECK(bin_pool.Allocate(static_cast<long long>(this->edges), workgroups, MARK_PREDECESSORS, d_overflow),
+                     "BFSProblem bin pool allocation failed");
+        if (!ds->d_fresh) {
+            const size_t bytes = (static_cast<size_t>(this->nodes) + 1023) / 1024 * 1024 + 1024;  // FreshToBitmapKernel reads 1 KiB steps
+            GR_CHECK(hipMalloc(&ds->d_fresh, bytes), "BFSProblem hipMalloc d_fresh failed");
+            GR_CHECK(hipMemset(ds->d_fresh, 0, bytes), "BFSProblem hipMemset d_fresh failed");  // levels leave it zero again
+        }
+        if (!ds->d_frontier_mask[0])
+            GR_CHECK(hipMalloc(&ds->d_frontier_mask[0], sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
+                     "BFSProblem hipMalloc d_frontier_mask failed");
+        return retval;
+    }
+
     hipError_t InverseIsSelf(float alpha_ = 0.0f, float beta_ = 0.0f)
     {
         return SetInverseGraph(this->graph_slices[0]->d_row_offsets, this->graph_slices[0]->d_column_indices, alpha_, beta_);

@@ -24,6 +24,8 @@
 #include <climits>
 #include <type_traits>
 
+#include <gunrock/oprtr/advance/binned.hpp>
+#include <gunrock/oprtr/advance/functor_hooks.hpp>
 #include <gunrock/oprtr/frontier_writer.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
@@ -49,33 +51,6 @@ struct KernelPolicy {
     static constexpr MODE ADVANCE_MODE = _ADVANCE_MODE;
 };
 
-// Optional functor hook: `static bool ScreenEdge(s_id, d_id, problem, e_id, e_id_in)` -- a side-effect-free
-// pre-test evaluated for all of a thread's edges before any CondEdge runs, so its loads overlap.  Functors
-// without it (the reference's functor shape, bfs_functor.cuh:49-88) are screened by `true`.
-template <typename Functor, typename VertexId, typename DataSlice, typename = void>
-struct HasScreenEdge : std::false_type {};
-template <typename Functor, typename VertexId, typename DataSlice>
-struct HasScreenEdge<Functor, VertexId, DataSlice,
-                     std::void_t<decltype(Functor::ScreenEdge(VertexId(), VertexId(), static_cast<DataSlice *>(nullptr),
-                                                              VertexId(), VertexId()))>> : std::true_type {};
-
-template <typename Functor, typename VertexId, typename DataSlice>
-__device__ __forceinline__ bool ScreenEdge(VertexId s, VertexId d, DataSlice *slice, VertexId e, VertexId e_in)
-{
-    if constexpr (HasScreenEdge<Functor, VertexId, DataSlice>::value) return Functor::ScreenEdge(s, d, slice, e, e_in);
-    else return true;
-}
-
-// Optional functor hook `ApplyEdgeWave(s_id, d_id, live, problem, e_id, e_id_in)`: called INSTEAD of ApplyEdge, by every lane
-// of the wave (live = this lane's edge passed CondEdge), so the functor may combine lanes -- consecutive lanes hold consecutive
-// edge slots, i.e. runs of the same source -- before it touches memory (BC's dependency sums: one atomic per run, not per edge).
-template <typename Functor, typename VertexId, typename DataSlice, typename = void>
-struct HasApplyEdgeWave : std::false_type {};
-template <typename Functor, typename VertexId, typename DataSlice>
-struct HasApplyEdgeWave<Functor, VertexId, DataSlice,
-                        std::void_t<decltype(Functor::ApplyEdgeWave(VertexId(), VertexId(), false, static_cast<DataSlice *>(nullptr),
-                                                                    VertexId(), VertexId()))>> : std::true_type {};
-
 template <typename VertexId, typename SizeT>
 struct AdvanceArgs {
     util::Frontier<VertexId, SizeT> in;
@@ -87,6 +62,7 @@ struct AdvanceArgs {
     unsigned long long *d_tail_out;    // packed tail of the output frontier
     unsigned long long *d_tail_clear;  // ring slot to zero for the step after next
     int *d_overflow;
+    BinPool<VertexId> bins;            // BINNED advance only (binned.hpp): where phase 1 hands its survivors
 };
 
 // Frontier-array load.  FRESH = the arrays were written earlier in the SAME launch (multi-level tail kernel): read
@@ -99,39 +75,69 @@ __device__ __forceinline__ T LoadQueue(const T *p)
     return *p;
 }
 
-template <typename KernelPolicy, typename VertexId, typename SizeT>
+struct NoWriterStorage {};
+
+template <typename KernelPolicy, typename VertexId, typename SizeT, bool WITH_WRITER = true>
 struct AdvanceShared {
     typedef FrontierWriter<KernelPolicy::THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
+    static constexpr int WAVES = KernelPolicy::THREADS / util::kWaveSize;
     SizeT scan[KernelPolicy::TILE];       // degree prefix relative to the tile's first slot
     SizeT row[KernelPolicy::TILE];        // first edge of the staged vertex
     VertexId vertex[KernelPolicy::TILE];  // staged vertex id
-    typename Writer::Storage writer;
-    int advance;                          // how far the frontier cursor moves after a tile
-    int owner_count[2][KernelPolicy::THREADS / util::kWaveSize];
+    unsigned own[KernelPolicy::TILE];     // slot -> (tile tag << IDX_BITS | staged entry whose row starts at this slot)
+    typename std::conditional<WITH_WRITER, typename Writer::Storage, NoWriterStorage>::type writer;
+    int owner_count[2][WAVES];
     unsigned long long level_tail;        // tail kernel: broadcast of the level's packed tail
-    unsigned long long wave_sum[KernelPolicy::THREADS / util::kWaveSize];  // COUNT_ONLY reduction
+    unsigned long long wave_sum[WAVES];   // COUNT_ONLY reduction
+    BinnerStorage binner;                 // BINNED: the workgroup's open chunks
 };
 
+constexpr int ILog2(int x) { return x <= 1 ? 0 : 1 + ILog2(x >> 1); }
+
+// Per-kernel state of the slot -> owner marks (see ExpandTiles): zero the marks once, then every tile uses a fresh tag.
+// Whole workgroup; a barrier must follow before the first ExpandTiles.
+template <typename KernelPolicy, typename Shared>
+__device__ __forceinline__ void InitOwnerMarks(Shared &sh, unsigned &tile_tag)
+{
+#pragma unroll
+    for (int k = 0; k < KernelPolicy::ITEMS; ++k) sh.own[k * KernelPolicy::THREADS + threadIdx.x] = 0u;
+    tile_tag = 0u;
+}
+
 // Expand the edge-slot tiles [tile_begin, tile_end) of the input frontier.  Whole workgroup calls; requires the writer
-// initialised and a barrier since.  On return all appends are complete and a barrier has passed (count is stable);
-// nothing has been flushed beyond what overflow protection forced.
+// initialised, InitOwnerMarks done and a barrier since.  On return all appends are complete and a barrier has passed (count
+// is stable); nothing has been flushed beyond what overflow protection forced.
 // OUT_WITH_DEGREES: the output is a full frontier (vertex, row start, degree prefix) ready for the next advance
 // (BFS); false = ids only, for outputs that pass through a filter / priority-queue split first (SSSP).
 // COUNT_ONLY: accepted destinations are only counted (into `accepted`), nothing is enqueued -- for a level whose output
 // frontier will be consumed as a bitmap (the bottom-up direction) and needs neither ids nor degrees.
-template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH, bool COUNT_ONLY = false>
+// BINNED (with COUNT_ONLY): phase 1 of the destination-binned advance (binned.hpp) -- edges that pass ScreenEdge are handed to
+// the bin of their destination's owner XCD; CondEdge / ApplyEdge run in phase 2.  The caller has initialised sh.binner.
+//
+// Slot -> owner without a search per slot.  The reference binary-searches the staged degree prefix for every output slot
+// (edge_map_partitioned/kernel.cuh:369-392); on a low-degree frontier (R-MAT level 2: 6.6 M vertices of degree ~22) that is
+// 6 dependent LDS round trips per edge and it bounded the kernel.  Here the thread that stages frontier entry j also drops
+// the mark (tag | j) at the slot where j's row begins; a wave owns ITEMS x 64 CONSECUTIVE slots, finds the owner of its
+// first slot with one (wave-uniform) search and resolves the rest with an inclusive max-scan over the marks on the DPP
+// path.  Tags make stale marks of earlier tiles lose every max, so the marks are never cleared.
+template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH, bool COUNT_ONLY = false,
+          bool BINNED = false, typename Shared>
 __device__ __forceinline__ void ExpandTiles(
     const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a, typename ProblemData::DataSlice &slice,
-    const long long tile_begin, const long long tile_end,
-    AdvanceShared<KernelPolicy, typename ProblemData::VertexId, typename ProblemData::SizeT> &sh, unsigned &accepted)
+    const long long tile_begin, const long long tile_end, Shared &sh, unsigned &accepted, unsigned &tile_tag)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
     constexpr int THREADS = KernelPolicy::THREADS;
     constexpr int TILE = KernelPolicy::TILE;
     constexpr int ITEMS = KernelPolicy::ITEMS;
+    constexpr int IDX_BITS = ILog2(TILE);
+    static_assert((1 << IDX_BITS) == TILE, "tile size must be a power of two");
+    constexpr unsigned MAX_TAG = (1u << (32 - IDX_BITS)) - 1u;
     typedef FrontierWriter<THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
     const int tid = threadIdx.x;
+    const unsigned lane = util::LaneId();
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid / util::kWaveSize) * (util::kWaveSize * ITEMS);  // first slot of this wave
     const long long total = a.in_edges;
 
     // Frontier cursor: largest i with scan[i] <= first slot of this range (zero-degree vertices are never enqueued,
@@ -142,7 +148,6 @@ __device__ __forceinline__ void ExpandTiles(
         // 64-ary search, one probe per lane and round: a frontier of 3 M entries takes 4 dependent round trips instead of the
         // 22 of a binary search (every workgroup pays this chain before its first tile; it was ~10 us of a 46 us launch).
         SizeT lo = 0, hi = a.in_len;  // invariant: scan[lo] <= first_slot < scan[hi] (scan[in_len] = total)
-        const unsigned lane = util::LaneId();
         while (hi - lo > 1) {
             const SizeT step = (hi - lo + util::kWaveSize - 1) / util::kWaveSize;
             const long long idx = static_cast<long long>(lo) + static_cast<long long>(lane) * step;
@@ -155,20 +160,40 @@ __device__ __forceinline__ void ExpandTiles(
         cursor = lo;
     }
 
+    // the first THREADS entries of the next tile's frontier slice, fetched one tile ahead (not in the single-workgroup FRESH
+    // form, which re-reads queue arrays written earlier in the same launch)
+    SizeT p_scan = INT_MAX, p_row = 0;
+    VertexId p_v = 0;
+    if (!FRESH && tile_begin < tile_end && cursor + tid < a.in_len) {
+        p_scan = a.in.scan[cursor + tid];
+        p_row = a.in.row_start[cursor + tid];
+        p_v = a.in.v[cursor + tid];
+    }
+
     for (long long tile = tile_begin; tile < tile_end; ++tile) {
         const SizeT slot0 = static_cast<SizeT>(tile * TILE);
         const int slots = (total - tile * TILE < TILE) ? static_cast<int>(total - tile * TILE) : TILE;
+        if (++tile_tag > MAX_TAG) {  // (uniform) tags exhausted: forget every mark and start over
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) sh.own[k * THREADS + tid] = 0u;
+            tile_tag = 1u;
+            __syncthreads();
+        }
+        const unsigned tag = tile_tag << IDX_BITS;
 
         // Appends of the previous tile are complete (barrier at the end of the loop body / after the
         // cursor search); every thread reads the count here, before this tile's first barrier, and the
         // next Append comes after it.
-        const int pending = Writer::Count(sh.writer);
+        int pending = 0;
+        if constexpr (!COUNT_ONLY) pending = Writer::Count(sh.writer);
 
         // ---- stage the covering frontier slice, THREADS entries per round ----
         // sh.scan holds the prefix relative to the tile (negative for a row that began in an earlier
         // tile); entries past the slice keep their true value (>= slots), INT_MAX past the frontier.
         // `owners` counts the staged entries that own at least one slot of this tile (a prefix of the
-        // staged entries, because the degree prefix is increasing).
+        // staged entries, because the degree prefix is increasing).  Entry 0 is the owner of slot 0 (its row may have begun
+        // in an earlier tile); every later owner starts inside the tile and marks its first slot.
         int staged = 0;
         int owners = 0;
         if (FRESH) {
@@ -195,6 +220,7 @@ __device__ __forceinline__ void ExpandTiles(
                 if (rel[r] < slots) {
                     sh.row[r * THREADS + tid] = rw[r];
                     sh.vertex[r * THREADS + tid] = vx[r];
+                    if (rel[r] > 0) sh.own[rel[r]] = tag | static_cast<unsigned>(r * THREADS + tid);
                 }
                 wave_owners += __popcll(__ballot(rel[r] < slots));
             }
@@ -205,14 +231,24 @@ __device__ __forceinline__ void ExpandTiles(
             for (int w = 0; w < THREADS / util::kWaveSize; ++w) owners += sh.owner_count[0][w];
         } else
         for (int base = 0, round = 0; base < TILE; base += THREADS, ++round) {
-            const SizeT idx = cursor + base + tid;
-            SizeT rel = INT_MAX;
-            if (idx < a.in_len) {
-                rel = LoadQueue<FRESH>(a.in.scan + idx) - slot0;
-                if (rel < slots) {
-                    sh.row[base + tid] = LoadQueue<FRESH>(a.in.row_start + idx);
-                    sh.vertex[base + tid] = LoadQueue<FRESH>(a.in.v + idx);
+            // round 0 was fetched while the previous tile was being expanded; later rounds (rows of degree < ~4) load here.
+            // Row start and vertex are loaded together with the prefix, not after the in-tile test: one round trip, not two.
+            SizeT abs_scan = p_scan, rw = p_row;
+            VertexId vx = p_v;
+            if (round > 0) {
+                const SizeT idx = cursor + base + tid;
+                abs_scan = INT_MAX;
+                if (idx < a.in_len) {
+                    abs_scan = a.in.scan[idx];
+                    rw = a.in.row_start[idx];
+                    vx = a.in.v[idx];
                 }
+            }
+            const SizeT rel = (abs_scan == INT_MAX) ? INT_MAX : abs_scan - slot0;
+            if (rel < slots) {
+                sh.row[base + tid] = rw;
+                sh.vertex[base + tid] = vx;
+                if (rel > 0) sh.own[rel] = tag | static_cast<unsigned>(base + tid);
             }
             sh.scan[base + tid] = rel;
             const unsigned long long in_tile = __ballot(rel < slots);
@@ -225,81 +261,110 @@ __device__ __forceinline__ void ExpandTiles(
             owners += here;
             if (here < THREADS) break;  // uniform: slice ended inside this round
         }
-        if (!COUNT_ONLY && pending > KernelPolicy::STAGE_CAPACITY - TILE) {
-            if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
-            else Writer::FlushIds(sh.writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+        if constexpr (!COUNT_ONLY) {
+            if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
+                if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+                else Writer::FlushIds(sh.writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+            }
         }
 
-        // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
-        // lane-strided slots => one wave-instruction reads 256 contiguous bytes of column_indices
+        // ---- where the next tile starts: the owner of slot `slots` is the last owner of this tile, or the staged entry
+        //      right behind it when that entry's row begins exactly at the tile boundary.  (Degrees are >= 1, so a full stage
+        //      of degree-1 rows is the one case LDS cannot answer: the next queue entry decides.) ----
+        int advance = owners - 1;
+        if (owners < staged) {
+            if (sh.scan[owners] == slots) advance = owners;
+        } else {  // owners == staged == TILE
+            const SizeT next = cursor + TILE;
+            if (next < a.in_len && LoadQueue<FRESH>(a.in.scan + next) - slot0 == slots) advance = TILE;
+        }
+        if (!FRESH && tile + 1 < tile_end) {  // next tile's slice: in flight while this tile expands
+            const SizeT idx = cursor + advance + tid;
+            p_scan = INT_MAX;
+            if (idx < a.in_len) {
+                p_scan = a.in.scan[idx];
+                p_row = a.in.row_start[idx];
+                p_v = a.in.v[idx];
+            }
+        }
+
+        // ---- slot -> owner: one wave-uniform search for the wave's first slot, then a max-scan over the marks ----
         SizeT edge[ITEMS];
         VertexId src[ITEMS];
         VertexId dst[ITEMS];
         bool live[ITEMS];
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {  // owner search in LDS
-            const int slot = k * THREADS + tid;
-            live[k] = slot < slots;
-            int lo = 0, hi = owners;  // sh.scan[lo] <= slot < sh.scan[hi] (hi == owners: past the slice)
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (sh.scan[mid] <= slot) lo = mid; else hi = mid;
+        {
+            int lo = 0, hi = owners;  // sh.scan[lo] <= wave_base < sh.scan[hi] (hi == owners: past the slice)
+            if (wave_base > 0) {
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh.scan[mid] <= wave_base) lo = mid; else hi = mid;
+                }
             }
-            edge[k] = sh.row[lo] + (slot - sh.scan[lo]);
-            src[k] = sh.vertex[lo];
+            unsigned carry = tag | static_cast<unsigned>(lo);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int slot = wave_base + k * util::kWaveSize + static_cast<int>(lane);
+                live[k] = slot < slots;
+                unsigned m = sh.own[slot];
+                if (lane == 0) m = max(m, carry);
+                m = util::WaveInclusiveMaxDpp(m);
+                carry = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(m), util::kWaveSize - 1));
+                const int owner = static_cast<int>(m & static_cast<unsigned>(TILE - 1));
+                edge[k] = sh.row[owner] + (slot - sh.scan[owner]);
+                src[k] = sh.vertex[owner];
+            }
         }
+        // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
+        // consecutive lanes hold consecutive slots => one wave-instruction reads 256 contiguous bytes of column_indices
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(-1);
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k)  // side-effect-free screen: all status loads in flight together
-            live[k] = live[k] && ScreenEdge<Functor>(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
-            live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
+            live[k] = live[k] && ScreenEdge<Functor>(src[k], dst[k], &slice, edge[k],
+                                                     slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
         int mine = 0;
-        if constexpr (HasApplyEdgeWave<Functor, VertexId, typename ProblemData::DataSlice>::value) {
+        if constexpr (BINNED) {
+            static_assert(!BINNED || COUNT_ONLY, "a binned advance enqueues nothing itself");
+            Binner<THREADS, ITEMS, VertexId, ProblemData::MARK_PREDECESSORS>::Put(sh.binner, a.bins, src, dst, live);
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {  // every lane calls: the functor works across the wave
-                Functor::ApplyEdgeWave(src[k], dst[k], live[k], &slice, edge[k], slot0 + k * THREADS + tid);
-                mine += live[k] ? 1 : 0;
-            }
+            for (int k = 0; k < ITEMS; ++k) mine += live[k] ? 1 : 0;
         } else {
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                if (live[k]) {
-                    Functor::ApplyEdge(src[k], dst[k], &slice, edge[k], slot0 + k * THREADS + tid);
-                    ++mine;
+            for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
+                live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k],
+                                                       slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+            if constexpr (HasApplyEdgeWave<Functor, VertexId, typename ProblemData::DataSlice>::value) {
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) {  // every lane calls: the functor works across the wave
+                    Functor::ApplyEdgeWave(src[k], dst[k], live[k], &slice, edge[k],
+                                           slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+                    mine += live[k] ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) {
+                    if (live[k]) {
+                        Functor::ApplyEdge(src[k], dst[k], &slice, edge[k],
+                                           slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+                        ++mine;
+                    }
                 }
             }
         }
         accepted += static_cast<unsigned>(mine);
-        if (!COUNT_ONLY) {  // one LDS reservation per wave per tile
+        if constexpr (!COUNT_ONLY) {  // one LDS reservation per wave per tile
             int pos = Writer::Reserve(sh.writer, mine);
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k)
                 if (live[k]) sh.writer.buf[pos++] = dst[k];
         }
 
-        // ---- move the cursor to the owner of the next tile's first slot ----
-        // Degrees are >= 1, so sh.scan[j] >= j for j >= 1 and TILE staged entries always cover the tile
-        // PROVIDED the cursor is exact.  The owner is the last staged entry with prefix <= slots; the one
-        // case LDS cannot answer is a full stage of degree-1 rows, where the next entry decides.
-        if (tid == 0) {
-            int lo = 0, hi = staged;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (sh.scan[mid] <= slots) lo = mid; else hi = mid;
-            }
-            if (lo == TILE - 1) {
-                const SizeT next = cursor + TILE;
-                if (next < a.in_len && LoadQueue<FRESH>(a.in.scan + next) - slot0 == slots) lo = TILE;
-            }
-            sh.advance = lo;
-        }
-        __syncthreads();
-        cursor += sh.advance;
+        __syncthreads();  // every wave is done with the staged slice (and its appends are complete)
+        cursor += advance;
+        if constexpr (BINNED)  // chunks that filled up are rotated; the next tile's staging barrier orders this before its Put
+            Binner<THREADS, ITEMS, VertexId, ProblemData::MARK_PREDECESSORS>::EndTile(sh.binner, a.bins);
     }
-
 }
 
 template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES = true, bool COUNT_ONLY = false>
@@ -309,12 +374,14 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
-    typedef AdvanceShared<KernelPolicy, VertexId, SizeT> Shared;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT, !COUNT_ONLY> Shared;
     typedef typename Shared::Writer Writer;
     __shared__ Shared sh;
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
-    Writer::Init(sh.writer);
+    if constexpr (!COUNT_ONLY) Writer::Init(sh.writer);
+    unsigned tile_tag;
+    InitOwnerMarks<KernelPolicy>(sh, tile_tag);
 
     const long long tiles = (static_cast<long long>(a.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
     const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
@@ -324,9 +391,9 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     __syncthreads();                     // writer count initialised
 
     unsigned accepted = 0;
-    ExpandTiles<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, false, COUNT_ONLY>(a, slice, tile_begin, tile_end, sh, accepted);
+    ExpandTiles<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, false, COUNT_ONLY>(a, slice, tile_begin, tile_end, sh, accepted, tile_tag);
 
-    if (COUNT_ONLY) {  // workgroup total -> one atomic on the packed tail (edge half stays 0)
+    if constexpr (COUNT_ONLY) {  // workgroup total -> one atomic on the packed tail (edge half stays 0)
         unsigned long long sum = util::WaveSum(static_cast<unsigned long long>(accepted));
         if ((threadIdx.x & (util::kWaveSize - 1)) == 0) sh.wave_sum[threadIdx.x / util::kWaveSize] = sum;
         __syncthreads();
@@ -336,13 +403,60 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
             for (int w = 0; w < KernelPolicy::THREADS / util::kWaveSize; ++w) total += sh.wave_sum[w];
             if (total && a.d_tail_out) atomicAdd(a.d_tail_out, total);  // (nullptr: the caller does not want the count)
         }
-        return;
+    } else {
+        // final flush (ExpandTiles ended on a barrier: all appends complete, count is stable)
+        const int rest = Writer::Count(sh.writer);
+        __syncthreads();
+        if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
+        else Writer::FlushIds(sh.writer, rest, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
     }
-    // final flush (ExpandTiles ended on a barrier: all appends complete, count is stable)
-    const int rest = Writer::Count(sh.writer);
+}
+
+// ---- phase 1 of the destination-binned advance (binned.hpp): expand + ScreenEdge, survivors go to their owner XCD's bin ----
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void BinnedExpandKernel(
+    AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a,
+    typename ProblemData::DataSlice slice)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT, false> Shared;
+    typedef Binner<KernelPolicy::THREADS, KernelPolicy::ITEMS, VertexId, ProblemData::MARK_PREDECESSORS> Bins;
+    __shared__ Shared sh;
+    unsigned tile_tag;
+    InitOwnerMarks<KernelPolicy>(sh, tile_tag);
+
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
+    const long long tiles = (static_cast<long long>(a.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
+    const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
+    const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
+    if (tile_begin >= tile_end) return;  // workgroup-uniform: no chunk taken
+    BinnerStorage &bins = sh.binner;
+    Bins::Init(bins, a.bins);
     __syncthreads();
-    if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
-    else Writer::FlushIds(sh.writer, rest, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
+
+    unsigned accepted = 0;
+    ExpandTiles<KernelPolicy, ProblemData, Functor, false, false, true, true>(a, slice, tile_begin, tile_end, sh, accepted, tile_tag);
+    Bins::Finish(bins, a.bins);  // (ExpandTiles ended on a barrier + EndTile by the same threads)
+}
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+hipError_t LaunchBinned(const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
+                        const typename ProblemData::DataSlice &slice, const typename ProblemData::DataSlice &apply_slice,
+                        int max_grid_size, int apply_grid, hipStream_t stream)
+{
+    if (args.in_len <= 0 || args.in_edges <= 0) return hipSuccess;
+    const long long tiles = (static_cast<long long>(args.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    long long grid = tiles < max_grid_size ? tiles : max_grid_size;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((BinnedExpandKernel<KernelPolicy, ProblemData, Functor>), dim3(static_cast<unsigned>(grid)),
+                       dim3(KernelPolicy::THREADS), 0, stream, args, slice);
+    hipError_t rc = util::GRError("advance::BinnedExpandKernel launch failed", __FILE__, __LINE__);
+    if (rc) return rc;
+    hipLaunchKernelGGL((BinnedApplyKernel<256, ProblemData, Functor, ProblemData::MARK_PREDECESSORS>), dim3(apply_grid), dim3(256), 0,
+                       stream, args.bins, apply_slice);
+    return util::GRError("advance::BinnedApplyKernel launch failed", __FILE__, __LINE__);
 }
 
 // ---- multi-level tail: ONE workgroup runs consecutive BSP levels while the frontier stays small ----
@@ -378,6 +492,8 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void TailLevelsKernel(
     __shared__ Shared sh;
 
     Writer::Init(sh.writer);
+    unsigned tile_tag;
+    InitOwnerMarks<KernelPolicy>(sh, tile_tag);
     int selector = t.selector;
     long long iteration = t.first_iteration;
     int done = 0;
@@ -407,7 +523,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void TailLevelsKernel(
 
         const long long tiles = (static_cast<long long>(edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
         unsigned accepted = 0;
-        ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, 0, tiles, sh, accepted);
+        ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, 0, tiles, sh, accepted, tile_tag);
         const int rest = Writer::Count(sh.writer);
         __syncthreads();
         Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
@@ -511,6 +627,8 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
     const TailArgs<VertexId, SizeT> &t = p.t;
 
     Writer::Init(sh.writer);
+    unsigned tile_tag;
+    InitOwnerMarks<KernelPolicy>(sh, tile_tag);
     int selector = t.selector;
     long long iteration = t.first_iteration;
     long long unexplored = p.unexplored_edges;
@@ -555,7 +673,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
         const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
         if (tile_begin < tile_end) {  // workgroup-uniform
             unsigned accepted = 0;
-            ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, tile_begin, tile_end, sh, accepted);
+            ExpandTiles<KernelPolicy, ProblemData, Functor, true, true>(a, slice, tile_begin, tile_end, sh, accepted, tile_tag);
             const int rest = Writer::Count(sh.writer);
             __syncthreads();
             Writer::template Flush<true>(sh.writer, rest, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);

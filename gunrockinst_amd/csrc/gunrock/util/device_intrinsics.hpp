@@ -40,6 +40,35 @@ __device__ __forceinline__ T WaveInclusiveSum(T x)
     return x;
 }
 
+// ---- wave64 scans on the DPP data path (no LDS crossbar traffic, ~6 VALU instructions) ----
+// row_shr:1,2,4,8 scan the four 16-lane rows, row_bcast:15 / row_bcast:31 carry the row totals across (gfx9 DPP controls;
+// lanes without a source keep `identity`).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned DppFrom(unsigned identity, unsigned x)
+{
+    return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(x), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ unsigned WaveInclusiveSumDpp(unsigned x)
+{
+    x += DppFrom<0x111, 0xF>(0u, x);
+    x += DppFrom<0x112, 0xF>(0u, x);
+    x += DppFrom<0x114, 0xF>(0u, x);
+    x += DppFrom<0x118, 0xF>(0u, x);
+    x += DppFrom<0x142, 0xA>(0u, x);
+    x += DppFrom<0x143, 0xC>(0u, x);
+    return x;
+}
+__device__ __forceinline__ unsigned WaveInclusiveMaxDpp(unsigned x)
+{
+    x = max(x, DppFrom<0x111, 0xF>(0u, x));
+    x = max(x, DppFrom<0x112, 0xF>(0u, x));
+    x = max(x, DppFrom<0x114, 0xF>(0u, x));
+    x = max(x, DppFrom<0x118, 0xF>(0u, x));
+    x = max(x, DppFrom<0x142, 0xA>(0u, x));
+    x = max(x, DppFrom<0x143, 0xC>(0u, x));
+    return x;
+}
+
 template <typename T>
 __device__ __forceinline__ T WaveSum(T x)
 {

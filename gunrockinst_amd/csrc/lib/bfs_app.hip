@@ -32,6 +32,7 @@ struct BfsRunner {
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual void SetPersistentLimit(int limit) = 0;
+    virtual void SetBinnedMinEdges(long long min_edges) = 0;
     virtual void SetHeadPass(int min_edges, int max_edges) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
@@ -71,6 +72,7 @@ struct BfsRunnerT : BfsRunner {
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
     }
     void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
+    void SetBinnedMinEdges(long long min_edges) override { problem.binned_min_edges = min_edges; }
     void SetHeadPass(int min_edges, int max_edges) override
     {
         problem.head_pass_min_edges = min_edges;
@@ -212,6 +214,13 @@ int grx_bfs_set_head_pass(grx_bfs *p, int min_edges, int max_edges)
 {
     if (!p || !p->runner || min_edges < -1 || max_edges < -1) return 1;
     p->runner->SetHeadPass(min_edges, max_edges);
+    return 0;
+}
+
+int grx_bfs_set_binned_min_edges(grx_bfs *p, long long min_edges)
+{
+    if (!p || !p->runner || min_edges < 0) return 1;
+    p->runner->SetBinnedMinEdges(min_edges);
     return 0;
 }
 

@@ -313,3 +313,31 @@ def test_directed_graph_new_level_kinds(min_edges, lite_factor, beta):
                 labels, preds = p.extract()
                 _check(g, src, labels, preds, p.stats())
             p.close()
+
+
+@pytest.mark.parametrize("min_edges,tail_limit", [(1, 0), (1, 8192), (5000, 8192), (1 << 40, 8192)])
+def test_binned_advance_parity(min_edges, tail_limit):
+    # destination-binned top-down levels (expand + screen -> per-XCD bins -> claims without atomics -> closing sweep) forced at
+    # small scale in all four modes and both traversal schedules; the last parameter set switches the path off
+    graphs = []
+    for scale, ef, und in [(12, 8, True), (16, 16, True), (18, 8, True), (15, 8, False)]:
+        g = o.rmat_seeded(scale, ef << scale, undirected=und)
+        deg = np.diff(g.row_offsets)
+        graphs.append((g, und, [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist()))
+    hub = 70000                                          # one row far larger than a tile and a chunk
+    graphs.append((o.Csr(hub, np.concatenate(([0], np.full(hub, hub - 1, dtype=np.int32))), np.arange(1, hub, dtype=np.int32)),
+                   False, [0]))
+    for g, und, srcs in graphs:
+        for mark_pred, idempotence in MODES:
+            p = ga.BfsProblem(mark_pred, idempotence).init(g.nodes, g.row_offsets, g.col_indices)
+            if und:
+                p.set_inverse_graph()
+            p.set_tuning(tail_edge_limit=tail_limit)
+            p.set_binned_min_edges(min_edges)
+            for src in srcs:
+                for mode in ((0, 2) if und else (0,)):
+                    p.reset(int(src))
+                    p.enact(int(src), traversal_mode=mode)
+                    labels, preds = p.extract()
+                    _check(g, int(src), labels, preds, p.stats())
+            p.close()
