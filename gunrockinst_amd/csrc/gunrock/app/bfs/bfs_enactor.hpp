@@ -61,6 +61,12 @@ class BFSEnactor : public EnactorBase {
 #define GRX_LB_ITEMS 4
 #endif
     typedef oprtr::advance::KernelPolicy<256, GRX_LB_ITEMS, 8, oprtr::advance::LB> LBAdvancePolicy;
+    // Phase 1 of a binned level: 8 edge slots per thread in flight (a tile's column loads, status probes and pair stores are
+    // dependent round trips of a few microseconds each under load: what hides them is bytes in flight per CU).
+#ifndef GRX_BINNED_ITEMS
+#define GRX_BINNED_ITEMS 8
+#endif
+    typedef oprtr::advance::KernelPolicy<256, GRX_BINNED_ITEMS, 8, oprtr::advance::LB> BinnedPolicy;
     // Multi-level tail: one 1024-thread workgroup keeps expanding levels while a level has at most this many edges.
     typedef oprtr::advance::KernelPolicy<1024, 4, 1, oprtr::advance::LB> TailPolicy;
     // Persistent mid-size levels: 1024-thread workgroups (one edge slot per thread: the level is latency-bound, so spread it
@@ -446,8 +452,8 @@ class BFSEnactor : public EnactorBase {
                 }
                 if (problem->binned_min_edges > 0 && static_cast<long long>(queue_edges) >= problem->binned_min_edges) {
                     // ---- destination-binned level (oprtr/advance/binned.hpp): no claim atomics ----
-                    int expand_grid = util::ResidentGrid(oprtr::advance::BinnedExpandKernel<AdvancePolicy, BFSProblem, BfsFunctor>,
-                                                         AdvancePolicy::THREADS);
+                    int expand_grid = util::ResidentGrid(oprtr::advance::BinnedExpandKernel<BinnedPolicy, BFSProblem, BfsFunctor>,
+                                                         BinnedPolicy::THREADS);
                     if (max_grid_size > 0) expand_grid = max_grid_size;
                     const int apply_grid = util::ResidentGrid(
                         oprtr::advance::BinnedApplyKernel<256, BFSProblem, BfsFunctor, BFSProblem::MARK_PREDECESSORS>, 256);
@@ -458,7 +464,7 @@ class BFSEnactor : public EnactorBase {
                     typename BFSProblem::DataSlice expand_slice = *ds, apply_slice = *ds;
                     expand_slice.lite = 3;  // phase 1: screen against the visited bitmap (constant during the level)
                     apply_slice.lite = 2;   // phase 2: screen + claim on the destination's flag byte, on its owner XCD
-                    retval = oprtr::advance::LaunchBinned<AdvancePolicy, BFSProblem, BfsFunctor>(args, expand_slice, apply_slice,
+                    retval = oprtr::advance::LaunchBinned<BinnedPolicy, BFSProblem, BfsFunctor>(args, expand_slice, apply_slice,
                                                                                                expand_grid, apply_grid, stream);
                     if (retval) break;
                     // closing sweep: flag bytes -> labels (vertex order), visited bitmap, this level's discoveries as a bitmap ...

@@ -31,18 +31,22 @@ struct BFSFunctor {
     static __device__ __forceinline__ bool ScreenEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,
                                                       VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-        // L1-bypassing load (global_load sc1, served by the XCD's L2): a line parked in this CU's L1 is never refreshed
-        // during the launch, so hot words (hubs) would keep reading "unvisited" and every edge into a hub discovered on
-        // this level would pay a memory-side atomic -- measured: the heavy top-down levels were atomic-bound.
-        // phase 2 of a binned level (oprtr/advance/binned.hpp): this workgroup runs on the XCD that owns d_id's flag byte, so a
-        // load served by that XCD's L2 sees every earlier claim of the level
-        if (problem->lite == 2)
-            return __hip_atomic_load(problem->d_fresh + d_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-        // In the other lite modes (count-only level, phase 1 of a binned level) nothing writes the bitmap while the advance runs:
-        // plain loads, so the hub lines stay in L1.
-        const unsigned *wp = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
-        const unsigned word = problem->lite ? *wp : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (word & (1u << (d_id & 31))) == 0;        // still stale-tolerant: a miss only costs an atomic
+        // ONE branch-free 32-bit load at a (uniformly) selected address.  The advance calls this for a whole batch of edges before it
+        // looks at any result; a branch per edge would make the compiler wait for each load before issuing the next (measured:
+        // the probes of a tile then cost one memory round trip EACH instead of one together).
+        //  * lite == 2 -- phase 2 of a binned level (oprtr/advance/binned.hpp): the destination's flag byte; this workgroup runs
+        //    on the XCD that owns it, so a load served by that XCD's L2 sees every earlier claim of the level;
+        //  * otherwise the destination's bit of the visited bitmap.
+        // L1-bypassing (global_load sc1, served by the XCD's L2).  With atomic claims (lite == 0) a line parked in this CU's L1 is
+        // never refreshed during the launch, so hub words would keep reading "unvisited" and every edge into a hub discovered
+        // on this level would pay a memory-side atomic; in the lite modes the map is constant during the launch, but a random
+        // 4-byte probe of a 2 MiB map gains nothing from a 32 KiB L1 either (the plain load measured 1.5x slower).
+        const bool flags = problem->lite == 2;
+        const unsigned *base = flags ? reinterpret_cast<const unsigned *>(problem->d_fresh) : problem->d_visited_mask;
+        const unsigned index = static_cast<unsigned>(d_id) >> (flags ? 2 : 5);
+        const unsigned shift = flags ? (static_cast<unsigned>(d_id) & 3u) * 8u : (static_cast<unsigned>(d_id) & 31u);
+        const unsigned word = __hip_atomic_load(base + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((word >> shift) & (flags ? 0xFFu : 1u)) == 0;  // (bitmap: stale-tolerant, a miss only costs an atomic)
     }
 
     static __device__ __forceinline__ bool CondEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem,

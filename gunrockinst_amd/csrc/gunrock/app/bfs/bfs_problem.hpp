@@ -158,7 +158,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // Top-down levels with at least this many frontier edges run as a destination-binned advance (oprtr/advance/binned.hpp):
     // expand + screen, claims on the destination's owner XCD without atomics, then a vertex-ordered closing sweep
     // (FreshToBitmapKernel + BitmapToQueueKernel) that labels, dedupes and enqueues.  0 = never.
-    long long binned_min_edges = 1ll << 21;
+    long long binned_min_edges = 1ll << 23;
     oprtr::advance::BinPoolStorage<VertexId> bin_pool;
     int persistent_edge_limit = 1 << 20;  // ... and up to this many inside the persistent multi-workgroup kernel (0 = off)
     int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel

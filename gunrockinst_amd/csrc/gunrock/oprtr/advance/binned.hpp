@@ -100,11 +100,17 @@ struct Binner {
         if (c >= pool.max_chunks) {  // cannot happen with BinPoolChunks sizing; stay in bounds and fail loudly
             *pool.d_overflow = 1;
             c = pool.max_chunks - 1;
-        } else {
-            const int i = atomicAdd(pool.BinCount(b), 1);
-            pool.d_bin_list[static_cast<size_t>(b) * pool.max_chunks + i] = c;
         }
         return c;
+    }
+
+    // a chunk enters its bin's list when it is closed: phase 2 never sees empty or unused ones
+    static __device__ __forceinline__ void Close(const BinPool<VertexId> &pool, int b, int c, int count)
+    {
+        if (count <= 0) return;
+        pool.d_chunk_count[c] = count;
+        const int i = atomicAdd(pool.BinCount(b), 1);
+        if (i < pool.max_chunks) pool.d_bin_list[static_cast<size_t>(b) * pool.max_chunks + i] = c;
     }
 
     // whole workgroup; a barrier must follow before the first Put
@@ -178,7 +184,7 @@ struct Binner {
     {
         if (threadIdx.x < kBins && st.fill[threadIdx.x] >= kBinChunk) {
             const int b = threadIdx.x;
-            pool.d_chunk_count[st.chunk[b][0]] = kBinChunk;
+            Close(pool, b, st.chunk[b][0], kBinChunk);
             st.chunk[b][0] = st.chunk[b][1];
             st.fill[b] -= kBinChunk;
             st.chunk[b][1] = Grab(pool, b);
@@ -189,8 +195,7 @@ struct Binner {
     static __device__ __forceinline__ void Finish(Storage &st, const BinPool<VertexId> &pool)
     {
         if (threadIdx.x < kBins) {
-            pool.d_chunk_count[st.chunk[threadIdx.x][0]] = st.fill[threadIdx.x];
-            pool.d_chunk_count[st.chunk[threadIdx.x][1]] = 0;
+            Close(pool, threadIdx.x, st.chunk[threadIdx.x][0], st.fill[threadIdx.x]);
         }
     }
 };
@@ -205,37 +210,42 @@ __global__ __launch_bounds__(THREADS) void BinnedApplyKernel(BinPool<typename Pr
                                                              typename ProblemData::DataSlice slice)
 {
     typedef typename ProblemData::VertexId VertexId;
-    constexpr int BATCH = 8;  // pairs per thread whose loads are in flight together (a chunk = 2 batches of 256 x 8)
-    __shared__ int s_index[2];
+    // Every WAVE works on its own: it draws a chunk, sweeps it in batches of 64 x BATCH pairs with all loads of a batch in
+    // flight together, and never meets the other waves at a barrier (a round trip to memory costs microseconds under load;
+    // what this kernel needs is many of them overlapping).  The next chunk index is drawn before the current chunk is swept.
+    constexpr int BATCH = WITH_SRC ? 8 : 16;
+    const unsigned lane = util::LaneId();
     const unsigned home = XccId();
     for (int r = 0; r < kBins; ++r) {
         const int b = static_cast<int>((home + r) & (kBins - 1));
-        const int chunks = *pool.BinCount(b);
+        const int listed = *pool.BinCount(b);
+        const int chunks = listed < pool.max_chunks ? listed : pool.max_chunks;
         const int *list = pool.d_bin_list + static_cast<size_t>(b) * pool.max_chunks;
-        // chunk indices are drawn one round ahead, so the dequeue's round trip overlaps the previous chunk's work
-        if (threadIdx.x == 0) s_index[0] = atomicAdd(pool.BinCursor(b), 1);
-        for (int round = 0;; ++round) {
-            __syncthreads();  // s_index[round & 1] is set; the other slot is free again
-            const int i = s_index[round & 1];
-            if (i >= chunks) break;  // workgroup-uniform
-            if (threadIdx.x == 0) s_index[(round + 1) & 1] = atomicAdd(pool.BinCursor(b), 1);
+        // (a glance before drawing: the cursors are eight hot addresses, ~88 atomics per microsecond each)
+        if (__hip_atomic_load(pool.BinCursor(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chunks) continue;
+        int next = 0;
+        if (lane == 0) next = atomicAdd(pool.BinCursor(b), 1);
+        for (;;) {
+            const int i = __builtin_amdgcn_readfirstlane(next);
+            if (i >= chunks) break;  // wave-uniform
+            if (lane == 0) next = atomicAdd(pool.BinCursor(b), 1);  // (its latency hides behind this chunk's sweep)
             const int c = list[i];
             const int count = pool.d_chunk_count[c];
             const VertexId *dst = pool.d_dst + static_cast<size_t>(c) * kBinChunk;
             const VertexId *src = WITH_SRC ? pool.d_src + static_cast<size_t>(c) * kBinChunk : nullptr;
-            for (int j0 = 0; j0 < count; j0 += THREADS * BATCH) {
+            for (int j0 = 0; j0 < count; j0 += util::kWaveSize * BATCH) {
                 VertexId d[BATCH], s[BATCH];
                 bool ok[BATCH];
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
-                    const int j = j0 + k * THREADS + threadIdx.x;
+                    const int j = j0 + k * util::kWaveSize + static_cast<int>(lane);
                     ok[k] = j < count;
-                    d[k] = ok[k] ? dst[j] : 0;
-                    s[k] = (WITH_SRC && ok[k]) ? src[j] : 0;
+                    d[k] = ok[k] ? __builtin_nontemporal_load(dst + j) : 0;
+                    s[k] = (WITH_SRC && ok[k]) ? __builtin_nontemporal_load(src + j) : 0;
                 }
                 if constexpr (HasScreenEdge<Functor, VertexId, typename ProblemData::DataSlice>::value) {
 #pragma unroll
-                    for (int k = 0; k < BATCH; ++k) ok[k] = ok[k] && Functor::ScreenEdge(s[k], d[k], &slice, 0, 0);
+                    for (int k = 0; k < BATCH; ++k) ok[k] = ok[k] & Functor::ScreenEdge(s[k], d[k], &slice, 0, 0);  // (no branch)
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) ok[k] = ok[k] && Functor::CondEdge(s[k], d[k], &slice, 0, 0);
@@ -244,7 +254,6 @@ __global__ __launch_bounds__(THREADS) void BinnedApplyKernel(BinPool<typename Pr
                     if (ok[k]) Functor::ApplyEdge(s[k], d[k], &slice, 0, 0);
             }
         }
-        __syncthreads();  // everybody has left the round loop before s_index[0] is rewritten
     }
 }
 

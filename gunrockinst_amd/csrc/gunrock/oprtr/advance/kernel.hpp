@@ -81,10 +81,10 @@ template <typename KernelPolicy, typename VertexId, typename SizeT, bool WITH_WR
 struct AdvanceShared {
     typedef FrontierWriter<KernelPolicy::THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
     static constexpr int WAVES = KernelPolicy::THREADS / util::kWaveSize;
-    SizeT scan[KernelPolicy::TILE];       // degree prefix relative to the tile's first slot
-    SizeT row[KernelPolicy::TILE];        // first edge of the staged vertex
-    VertexId vertex[KernelPolicy::TILE];  // staged vertex id
-    unsigned own[KernelPolicy::TILE];     // slot -> (tile tag << IDX_BITS | staged entry whose row starts at this slot)
+    SizeT scan[KernelPolicy::THREADS];       // stage: degree prefix relative to the tile's first slot
+    SizeT row[KernelPolicy::THREADS];        // stage: first edge of the vertex
+    VertexId vertex[KernelPolicy::THREADS];  // stage: vertex id
+    unsigned own[KernelPolicy::TILE];        // slot -> (tile tag << IDX_BITS | staged entry whose row starts at this slot)
     typename std::conditional<WITH_WRITER, typename Writer::Storage, NoWriterStorage>::type writer;
     int owner_count[2][WAVES];
     unsigned long long level_tail;        // tail kernel: broadcast of the level's packed tail
@@ -131,8 +131,8 @@ __device__ __forceinline__ void ExpandTiles(
     constexpr int THREADS = KernelPolicy::THREADS;
     constexpr int TILE = KernelPolicy::TILE;
     constexpr int ITEMS = KernelPolicy::ITEMS;
-    constexpr int IDX_BITS = ILog2(TILE);
-    static_assert((1 << IDX_BITS) == TILE, "tile size must be a power of two");
+    constexpr int IDX_BITS = ILog2(THREADS);
+    static_assert((1 << IDX_BITS) == THREADS, "workgroup size must be a power of two");
     constexpr unsigned MAX_TAG = (1u << (32 - IDX_BITS)) - 1u;
     typedef FrontierWriter<THREADS, KernelPolicy::STAGE_CAPACITY, VertexId, SizeT> Writer;
     const int tid = threadIdx.x;
@@ -160,19 +160,23 @@ __device__ __forceinline__ void ExpandTiles(
         cursor = lo;
     }
 
-    // the first THREADS entries of the next tile's frontier slice, fetched one tile ahead (not in the single-workgroup FRESH
-    // form, which re-reads queue arrays written earlier in the same launch)
+    // A tile = up to TILE consecutive edge slots whose rows fit the stage (THREADS frontier entries): when more rows than that
+    // begin inside the TILE slots (rows of degree < ITEMS on average), the tile ends where the last staged row begins.
+    // The stage of the NEXT tile is fetched while this one expands (row start and vertex together with the prefix: one round
+    // trip, not two).
+    const long long slot_end = (tile_end * TILE < total) ? tile_end * TILE : total;
+    long long slot_at = tile_begin * TILE;
     SizeT p_scan = INT_MAX, p_row = 0;
     VertexId p_v = 0;
-    if (!FRESH && tile_begin < tile_end && cursor + tid < a.in_len) {
-        p_scan = a.in.scan[cursor + tid];
-        p_row = a.in.row_start[cursor + tid];
-        p_v = a.in.v[cursor + tid];
+    if (slot_at < slot_end && cursor + tid < a.in_len) {
+        p_scan = LoadQueue<FRESH>(a.in.scan + cursor + tid);
+        p_row = LoadQueue<FRESH>(a.in.row_start + cursor + tid);
+        p_v = LoadQueue<FRESH>(a.in.v + cursor + tid);
     }
 
-    for (long long tile = tile_begin; tile < tile_end; ++tile) {
-        const SizeT slot0 = static_cast<SizeT>(tile * TILE);
-        const int slots = (total - tile * TILE < TILE) ? static_cast<int>(total - tile * TILE) : TILE;
+    while (slot_at < slot_end) {
+        const SizeT slot0 = static_cast<SizeT>(slot_at);
+        const int limit = (slot_end - slot_at < TILE) ? static_cast<int>(slot_end - slot_at) : TILE;
         if (++tile_tag > MAX_TAG) {  // (uniform) tags exhausted: forget every mark and start over
             __syncthreads();
 #pragma unroll
@@ -188,103 +192,48 @@ __device__ __forceinline__ void ExpandTiles(
         int pending = 0;
         if constexpr (!COUNT_ONLY) pending = Writer::Count(sh.writer);
 
-        // ---- stage the covering frontier slice, THREADS entries per round ----
-        // sh.scan holds the prefix relative to the tile (negative for a row that began in an earlier
-        // tile); entries past the slice keep their true value (>= slots), INT_MAX past the frontier.
-        // `owners` counts the staged entries that own at least one slot of this tile (a prefix of the
-        // staged entries, because the degree prefix is increasing).  Entry 0 is the owner of slot 0 (its row may have begun
-        // in an earlier tile); every later owner starts inside the tile and marks its first slot.
-        int staged = 0;
+        // ---- stage the covering frontier slice ----
+        // sh.scan holds the prefix relative to the tile (<= 0 for entry 0, whose row may have begun in an earlier tile;
+        // INT_MAX past the frontier).  Entries with a prefix below `limit` are candidates to own slots of this tile (a prefix of
+        // the stage, because the degree prefix is increasing); every one but entry 0 marks the slot where its row begins.
+        {
+            const SizeT rel = (p_scan == INT_MAX) ? INT_MAX : p_scan - slot0;
+            sh.scan[tid] = rel;
+            if (rel < limit) {
+                sh.row[tid] = p_row;
+                sh.vertex[tid] = p_v;
+                if (rel > 0) sh.own[rel] = tag | static_cast<unsigned>(tid);
+            }
+            const unsigned long long in_tile = __ballot(rel < limit);
+            if (lane == 0) sh.owner_count[tile_tag & 1][tid / util::kWaveSize] = __popcll(in_tile);
+        }
+        if (FRESH) __syncthreads();
+        else util::LdsBarrier();  // (orders LDS only: the previous tile's global stores stay in flight)
         int owners = 0;
-        if (FRESH) {
-            // single-workgroup tail kernel: bandwidth is irrelevant, the chain of dependent round trips is everything, so all
-            // ITEMS rounds of the slice are fetched at once (a low-degree frontier otherwise costs one round trip per round)
-            SizeT rel[ITEMS], rw[ITEMS];
-            VertexId vx[ITEMS];
 #pragma unroll
-            for (int r = 0; r < ITEMS; ++r) {
-                const SizeT idx = cursor + r * THREADS + tid;
-                rel[r] = INT_MAX;
-                rw[r] = 0;
-                vx[r] = 0;
-                if (idx < a.in_len) {
-                    rel[r] = LoadQueue<true>(a.in.scan + idx) - slot0;
-                    rw[r] = LoadQueue<true>(a.in.row_start + idx);
-                    vx[r] = LoadQueue<true>(a.in.v + idx);
-                }
+        for (int w = 0; w < THREADS / util::kWaveSize; ++w) owners += sh.owner_count[tile_tag & 1][w];
+        int slots = limit;
+        if (owners == THREADS) {  // the stage is full of rows that begin inside the tile: cut the tile at the last one
+            slots = sh.scan[THREADS - 1];  // >= THREADS - 1 because degrees are >= 1: progress is guaranteed
+            owners = THREADS - 1;
+        }
+        // where the next tile starts: at this tile's last owner, or at the staged entry right behind it when that entry's row
+        // begins exactly at the tile's end
+        int advance = owners - 1;
+        if (sh.scan[owners] == slots) advance = owners;  // (owners < THREADS here)
+        {  // next tile's stage: in flight while this tile expands
+            const SizeT idx = cursor + advance + tid;
+            p_scan = INT_MAX;
+            if (slot_at + slots < slot_end && idx < a.in_len) {
+                p_scan = LoadQueue<FRESH>(a.in.scan + idx);
+                p_row = LoadQueue<FRESH>(a.in.row_start + idx);
+                p_v = LoadQueue<FRESH>(a.in.v + idx);
             }
-            int wave_owners = 0;
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r) {
-                sh.scan[r * THREADS + tid] = rel[r];
-                if (rel[r] < slots) {
-                    sh.row[r * THREADS + tid] = rw[r];
-                    sh.vertex[r * THREADS + tid] = vx[r];
-                    if (rel[r] > 0) sh.own[rel[r]] = tag | static_cast<unsigned>(r * THREADS + tid);
-                }
-                wave_owners += __popcll(__ballot(rel[r] < slots));
-            }
-            if ((tid & (util::kWaveSize - 1)) == 0) sh.owner_count[0][tid / util::kWaveSize] = wave_owners;
-            __syncthreads();
-            staged = TILE;
-#pragma unroll
-            for (int w = 0; w < THREADS / util::kWaveSize; ++w) owners += sh.owner_count[0][w];
-        } else
-        for (int base = 0, round = 0; base < TILE; base += THREADS, ++round) {
-            // round 0 was fetched while the previous tile was being expanded; later rounds (rows of degree < ~4) load here.
-            // Row start and vertex are loaded together with the prefix, not after the in-tile test: one round trip, not two.
-            SizeT abs_scan = p_scan, rw = p_row;
-            VertexId vx = p_v;
-            if (round > 0) {
-                const SizeT idx = cursor + base + tid;
-                abs_scan = INT_MAX;
-                if (idx < a.in_len) {
-                    abs_scan = a.in.scan[idx];
-                    rw = a.in.row_start[idx];
-                    vx = a.in.v[idx];
-                }
-            }
-            const SizeT rel = (abs_scan == INT_MAX) ? INT_MAX : abs_scan - slot0;
-            if (rel < slots) {
-                sh.row[base + tid] = rw;
-                sh.vertex[base + tid] = vx;
-                if (rel > 0) sh.own[rel] = tag | static_cast<unsigned>(base + tid);
-            }
-            sh.scan[base + tid] = rel;
-            const unsigned long long in_tile = __ballot(rel < slots);
-            if ((tid & (util::kWaveSize - 1)) == 0) sh.owner_count[round & 1][tid / util::kWaveSize] = __popcll(in_tile);
-            __syncthreads();
-            staged = base + THREADS;
-            int here = 0;
-#pragma unroll
-            for (int w = 0; w < THREADS / util::kWaveSize; ++w) here += sh.owner_count[round & 1][w];
-            owners += here;
-            if (here < THREADS) break;  // uniform: slice ended inside this round
         }
         if constexpr (!COUNT_ONLY) {
             if (pending > KernelPolicy::STAGE_CAPACITY - TILE) {
                 if (OUT_WITH_DEGREES) Writer::template Flush<true>(sh.writer, pending, a.out, a.d_tail_out, a.d_overflow, a.d_row_offsets);
                 else Writer::FlushIds(sh.writer, pending, a.out.v, a.out.capacity, a.d_tail_out, a.d_overflow);
-            }
-        }
-
-        // ---- where the next tile starts: the owner of slot `slots` is the last owner of this tile, or the staged entry
-        //      right behind it when that entry's row begins exactly at the tile boundary.  (Degrees are >= 1, so a full stage
-        //      of degree-1 rows is the one case LDS cannot answer: the next queue entry decides.) ----
-        int advance = owners - 1;
-        if (owners < staged) {
-            if (sh.scan[owners] == slots) advance = owners;
-        } else {  // owners == staged == TILE
-            const SizeT next = cursor + TILE;
-            if (next < a.in_len && LoadQueue<FRESH>(a.in.scan + next) - slot0 == slots) advance = TILE;
-        }
-        if (!FRESH && tile + 1 < tile_end) {  // next tile's slice: in flight while this tile expands
-            const SizeT idx = cursor + advance + tid;
-            p_scan = INT_MAX;
-            if (idx < a.in_len) {
-                p_scan = a.in.scan[idx];
-                p_row = a.in.row_start[idx];
-                p_v = a.in.v[idx];
             }
         }
 
@@ -310,7 +259,7 @@ __device__ __forceinline__ void ExpandTiles(
                 if (lane == 0) m = max(m, carry);
                 m = util::WaveInclusiveMaxDpp(m);
                 carry = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(m), util::kWaveSize - 1));
-                const int owner = static_cast<int>(m & static_cast<unsigned>(TILE - 1));
+                const int owner = static_cast<int>(m & static_cast<unsigned>(THREADS - 1));
                 edge[k] = sh.row[owner] + (slot - sh.scan[owner]);
                 src[k] = sh.vertex[owner];
             }
@@ -318,11 +267,16 @@ __device__ __forceinline__ void ExpandTiles(
         // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
         // consecutive lanes hold consecutive slots => one wave-instruction reads 256 contiguous bytes of column_indices
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(-1);
+        for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(0);
+        // side-effect-free screen, evaluated for EVERY slot (dead ones with vertex 0, edge 0) and combined without a branch, so
+        // the status loads of a tile are in flight together: `live && Screen()` would wait for each load before the next
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k)  // side-effect-free screen: all status loads in flight together
-            live[k] = live[k] && ScreenEdge<Functor>(src[k], dst[k], &slice, edge[k],
-                                                     slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+        for (int k = 0; k < ITEMS; ++k) {
+            const bool pass = ScreenEdge<Functor>(live[k] ? src[k] : static_cast<VertexId>(0), dst[k], &slice,
+                                                  live[k] ? edge[k] : static_cast<SizeT>(0),
+                                                  slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+            live[k] = live[k] & pass;
+        }
         int mine = 0;
         if constexpr (BINNED) {
             static_assert(!BINNED || COUNT_ONLY, "a binned advance enqueues nothing itself");
@@ -360,8 +314,10 @@ __device__ __forceinline__ void ExpandTiles(
                 if (live[k]) sh.writer.buf[pos++] = dst[k];
         }
 
-        __syncthreads();  // every wave is done with the staged slice (and its appends are complete)
+        if (FRESH) __syncthreads();  // every wave is done with the staged slice (and its appends are complete)
+        else util::LdsBarrier();     // same, without waiting for this tile's global stores (labels, binned pairs)
         cursor += advance;
+        slot_at += slots;
         if constexpr (BINNED)  // chunks that filled up are rotated; the next tile's staging barrier orders this before its Put
             Binner<THREADS, ITEMS, VertexId, ProblemData::MARK_PREDECESSORS>::EndTile(sh.binner, a.bins);
     }

@@ -27,6 +27,15 @@ __device__ __forceinline__ unsigned RankInMask(unsigned long long mask)
                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
 }
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its outstanding global stores.
+// __syncthreads() drains vmcnt too (s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier), i.e. a wave that has just issued scattered
+// global stores sits at the barrier for their full round trip (~3 us under load on MI355X) although nobody in the workgroup
+// will read them.  Use only where the barrier orders LDS traffic (and register-consumed loads) and nothing else.
+__device__ __forceinline__ void LdsBarrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Inclusive prefix sum across the 64 lanes of a wave (all lanes must call).
 template <typename T>
 __device__ __forceinline__ T WaveInclusiveSum(T x)

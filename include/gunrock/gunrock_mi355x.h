@@ -101,7 +101,7 @@ int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, i
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit);
 /* Top-down levels with at least `min_edges` frontier edges run as a destination-binned advance: expand + status screen,
  * claims on the destination's owner XCD without atomics, then a vertex-ordered closing sweep that labels and enqueues
- * (0 = never; default 2^21).  This replaces the per-edge atomicCAS of the reference's functor (bfs_functor.cuh:56-58) on the
+ * (0 = never; default 2^23).  This replaces the per-edge atomicCAS of the reference's functor (bfs_functor.cuh:56-58) on the
  * levels where it dominates.  Results do not depend on it. */
 int grx_bfs_set_binned_min_edges(grx_bfs *p, long long min_edges);
 /* Direction-optimizing only: a level that would run count-only or bottom-up and has between `min_edges` and `max_edges`
