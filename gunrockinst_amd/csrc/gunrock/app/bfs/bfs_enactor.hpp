@@ -179,10 +179,9 @@ class BFSEnactor : public EnactorBase {
         hipStream_t stream = gs->stream;
         if (src < 0 || src >= problem->nodes) return retval;
 
-        if ((retval = work_progress.Reset(stream))) return retval;
         unsigned queue_length = problem->SourceDegree() > 0 ? 1u : 0u;
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
-        if ((retval = work_progress.SetTail(0, queue_length, queue_edges, stream))) return retval;
+        if ((retval = work_progress.ResetWithTail(0, queue_length, queue_edges, stream))) return retval;
 
 #ifndef GRX_CONV_GRID_MULT
 #define GRX_CONV_GRID_MULT 2

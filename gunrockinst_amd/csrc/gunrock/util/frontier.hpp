@@ -96,6 +96,17 @@ static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned 
     if (lane == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One wave: what WorkProgress::Reset + SetTail do with three fill blits and one copy blit (4-5 us each, serialised at the
+// start of every Enact) -- zero the ring, the overflow flag and the wide tail, then seed one ring slot.
+static __global__ void ArmKernel(unsigned long long *d_tail, int *d_overflow, unsigned long long *d_wide, int slots, int wide_lines,
+                                 int wide_stride, int seed_slot, unsigned long long seed_value)
+{
+    const int lane = threadIdx.x;
+    if (lane < slots) d_tail[lane] = (lane == seed_slot) ? seed_value : 0ull;
+    if (lane < wide_lines) d_wide[lane * wide_stride] = 0ull;
+    if (lane == 0) *d_overflow = 0;
+}
+
 // Device words shared by all kernels of one enactor.
 struct WorkProgress {
     static constexpr int kSlots = 8;       // 0..3: BSP ring, 4: auxiliary tail, 5: SSSP far-min, 6: tail-kernel level count,
@@ -143,6 +154,15 @@ struct WorkProgress {
         GR_CHECK(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride, stream),
                  "WorkProgress memset failed");
         return retval;
+    }
+
+    // Reset + SetTail(slot, count, edges) in one launch
+    hipError_t ResetWithTail(int slot, unsigned count, unsigned edges, hipStream_t stream)
+    {
+        box->overflow = 0;  // (a new search starts: forget the last search's flag)
+        hipLaunchKernelGGL(ArmKernel, dim3(1), dim3(64), 0, stream, d_tail, d_overflow, d_wide, kSlots, kWideLines, kWideStride, slot & 3,
+                           PackTail(count, edges));
+        return GRError(hipGetLastError(), "WorkProgress ArmKernel launch failed", __FILE__, __LINE__);
     }
 
     hipError_t SetTail(int slot, unsigned count, unsigned edges, hipStream_t stream)
