@@ -107,27 +107,86 @@ def main():
         dist.destroy_process_group()
 
 
-_BFS_KERNELS = ("BfsResetKernel", "BitmapDiffKernel", "BitmapToQueueKernel", "BottomUpKernel", "FreshToBitmapKernel",
-                "LoadBalancedKernel", "PersistentLevelsKernel", "TailLevelsKernel", "QueueToBitmapKernel", "PublishKernel")
+_BFS_KERNELS = ("BfsResetKernel", "ArmKernel", "BitmapDiffKernel", "BitmapToQueueKernel", "BottomUpKernel", "BottomUpSparseKernel",
+                "FreshToBitmapKernel", "LoadBalancedKernel", "BinnedExpandKernel", "BinnedApplyKernel", "PersistentLevelsKernel",
+                "TailLevelsKernel", "QueueToBitmapKernel", "PublishKernel")
+PROFILE_TAG = "r02"
 
 
-def pmc_traffic_per_search():
-    """HBM-side bytes per BFS from the committed PMC passes of this same command (profiles/README.md): FETCH_SIZE and
-    WRITE_SIZE were collected in separate rocprofv3 runs and summed per kernel (KiB); searches = BfsResetKernel dispatches.
-    FETCH_SIZE is used RAW: on gfx950 it counts a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM)
-    and is uncalibrated for 4-byte gathers, so the true figure lies between fetch + write and 2 * fetch + write."""
+def source_fingerprint():
+    """sha1 over the kernel sources: profiles taken from other sources than the ones benchmarked are not quoted (the GPU box
+    has no .git, so the commit id itself is not available there)."""
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "gunrockinst_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        if os.sep + "build" in d:
+            continue
+        for f in sorted(files):
+            if f.endswith((".hpp", ".hip", ".h")):
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _short_kernel(name):
+    import re
+    name = name.split("(")[0].replace("void ", "")
+    return re.sub(r"<.*", "", name).split("::")[-1].strip()
+
+
+def profile_tables():
+    """Per-kernel figures from the committed rocprofv3 passes of THIS command (profiles/README.md): kernel-trace stats
+    (calls, average duration) and FETCH_SIZE / WRITE_SIZE from separate --pmc passes.  Returns None when the profiles are
+    missing or were taken from different kernel sources.
+    FETCH_SIZE is quoted RAW: on gfx950 it counts a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md,
+    HBM) and is uncalibrated for the 4-byte gathers that dominate a traversal, so the true read traffic lies between
+    fetch_raw and 2 * fetch_raw."""
+    import csv
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch_size.json")) as fh:
+        with open(os.path.join(pdir, PROFILE_TAG + "_profile_meta.json")) as fh:
+            meta = json.load(fh)
+        if meta.get("source_sha") != source_fingerprint():
+            return {"stale": True, "profiled_source_sha": meta.get("source_sha"), "source_sha": source_fingerprint()}
+        with open(os.path.join(pdir, PROFILE_TAG + "_bench_pmc_fetch_size.json")) as fh:
             fetch = json.load(fh)
-        with open(os.path.join(ROOT, "profiles", "r01_bench_pmc_write_size.json")) as fh:
+        with open(os.path.join(pdir, PROFILE_TAG + "_bench_pmc_write_size.json")) as fh:
             write = json.load(fh)
-        nf, nw = fetch["BfsResetKernel"]["dispatches"], write["BfsResetKernel"]["dispatches"]
-        fb = sum(fetch[k]["sum"] for k in _BFS_KERNELS if k in fetch) * 1024.0 / nf
-        wb = sum(write[k]["sum"] for k in _BFS_KERNELS if k in write) * 1024.0 / nw
-        return {"bytes": round(fb + wb), "fetch_raw": round(fb), "write": round(wb), "upper": round(2 * fb + wb),
-                "source": "profiles/r01_bench_pmc_{fetch,write}_size.json (separate rocprofv3 --pmc passes, per search)"}
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        stats = {}
+        with open(os.path.join(pdir, PROFILE_TAG + "_bench_kernel_stats.csv")) as fh:
+            for r in csv.DictReader(fh):
+                k = _short_kernel(r["Name"])
+                a = stats.setdefault(k, [0, 0.0])
+                a[0] += int(r["Calls"])
+                a[1] += float(r["TotalDurationNs"])
+    except (OSError, KeyError, ValueError):
         return None
+    searches_f = fetch.get("BfsResetKernel", {}).get("dispatches", 0)
+    searches_w = write.get("BfsResetKernel", {}).get("dispatches", 0)
+    if not searches_f or not searches_w:
+        return None
+    table = {}
+    fb = wb = 0.0
+    for k in _BFS_KERNELS:
+        f, w, st = fetch.get(k), write.get(k), stats.get(k)
+        if not f or not w:
+            continue
+        fpl = f["sum"] * 1024.0 / f["dispatches"]          # bytes per launch (the tool reports KiB)
+        wpl = w["sum"] * 1024.0 / w["dispatches"]
+        fb += f["sum"] * 1024.0 / searches_f
+        wb += w["sum"] * 1024.0 / searches_w
+        row = {"launches_per_search": round(f["dispatches"] / searches_f, 2), "fetch_raw_bytes_per_launch": round(fpl),
+               "write_bytes_per_launch": round(wpl)}
+        if st and st[0]:
+            avg_ns = st[1] / st[0]
+            row["avg_launch_us"] = round(avg_ns / 1e3, 2)
+            row["hbm_gbps_raw"] = round((fpl + wpl) / avg_ns, 1)
+            row["hbm_gbps_upper"] = round((2 * fpl + wpl) / avg_ns, 1)
+        table[k] = row
+    return {"stale": False, "source_sha": meta.get("source_sha"), "per_search": {"fetch_raw": round(fb), "write": round(wb),
+            "bytes": round(fb + wb), "upper": round(2 * fb + wb)}, "per_kernel": table,
+            "source": "profiles/%s_bench_{kernel_stats.csv,pmc_fetch_size.json,pmc_write_size.json}" % PROFILE_TAG}
 
 
 def bench_single(args, torch, ga, devgraph, device_index):
@@ -193,7 +252,8 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob.set_head_pass(args.head_pass_min, args.head_pass_max)
     names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel / BottomUpSparseKernel",
              2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
-             4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel"}
+             4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel",
+             7: "BinnedExpandKernel + BinnedApplyKernel + FreshToBitmapKernel + BitmapToQueueKernel (binned top-down)"}
     by_kind = {}
     kernel_ms, launches, balg = 0.0, 0, 0.0
     for k in range(min(args.steps, len(sources))):
@@ -214,18 +274,38 @@ def bench_single(args, torch, ga, devgraph, device_index):
             nv, ev = int(vis.sum()), int(deg[vis].sum())
         balg += 4.0 * ev + 20.0 * nv
     dom = max(by_kind, key=lambda kd: by_kind[kd][1]) if by_kind else 0
-    achieved = balg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # GB/s over all operator launches of a BFS
-    # (the committed PMC passes are of the default workload only)
-    pmc = pmc_traffic_per_search() if (mode == 2 and args.scale == 24 and args.edge_factor == 8 and args.seed == 0x6772) else None
+    n_inst = max(min(args.steps, len(sources)), 1)
+    # THE roofline figure (BASELINE.md section 4 / SURVEY 8(d)): algorithmic bytes of the searches / their Enact time
+    balg_timed = 4.0 * edges_total + 20.0 * nodes_total
+    achieved = balg_timed / (enact_ms * 1e-3) / 1e9 if enact_ms > 0 else 0.0
+    kernel_only = balg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # same bytes / summed operator-kernel event time
+    whole_step = balg_timed / wall / 1e9
+    prof = profile_tables() if (mode == 2 and args.scale == 24 and args.edge_factor == 8 and args.seed == 0x6772) else None
+    fresh = bool(prof) and not prof.get("stale")
+    kernel_s_per_search = (kernel_ms / n_inst) * 1e-3
+    phys = None
+    if fresh and kernel_s_per_search > 0:
+        phys = {"raw": round(prof["per_search"]["bytes"] / kernel_s_per_search / 8e12, 4),
+                "upper": round(prof["per_search"]["upper"] / kernel_s_per_search / 8e12, 4)}
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": pmc["bytes"] if pmc else None, "traffic_detail": pmc,
+                "frac": round(achieved / 8000.0, 5),
+                "definition": "algorithmic bytes (4*edges_visited + 20*nodes_visited) of the timed searches / their summed Enact "
+                              "time / 8 TB/s; a direction-optimizing search does not read most of those edges, so this is NOT "
+                              "the physical HBM rate (see hbm_frac_physical)",
+                "frac_kernel_only": round(kernel_only / 8000.0, 5),
+                "frac_whole_step": round(whole_step / 8000.0, 5),
+                "traffic": prof["per_search"]["bytes"] if fresh else None,
+                "traffic_detail": prof["per_search"] if fresh else (prof if prof else None),
+                "hbm_frac_physical": phys,
                 "kernel": names.get(dom, str(dom)),
                 "kernel_share_of_device_time": round(by_kind[dom][1] / kernel_ms, 4) if kernel_ms else None,
                 "kernel_launches": by_kind[dom][0] if by_kind else 0,
                 "kernel_avg_launch_ms": round(by_kind[dom][1] / max(by_kind[dom][0], 1), 5) if by_kind else None,
-                "all_launches": launches, "all_kernel_ms_per_bfs": round(kernel_ms / max(min(args.steps, len(sources)), 1), 5),
-                "alg_bytes_per_bfs": round(balg / max(min(args.steps, len(sources)), 1), 1),
-                "by_kernel_ms": {names.get(kd, str(kd)): round(v[1], 4) for kd, v in sorted(by_kind.items())}}
+                "all_launches": launches, "all_kernel_ms_per_bfs": round(kernel_ms / n_inst, 5),
+                "alg_bytes_per_bfs": round(balg / n_inst, 1),
+                "by_kernel_ms": {names.get(kd, str(kd)): round(v[1], 4) for kd, v in sorted(by_kind.items())},
+                "per_kernel": prof["per_kernel"] if fresh else None,
+                "profile_source": prof.get("source") if fresh else None}
     iprob.close()
 
     cpu = None

@@ -137,6 +137,12 @@ _SIGNATURES = {
     "grx_pbfs_bottom_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "grx_pbfs_bitmap_to_queue": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "grx_pbfs_labels": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_pbfs_preds": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "grx_pbfs_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "grx_pbfs_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "grx_pbfs_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "grx_pbfs_search": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "grx_pbfs_destroy": (None, [C.c_void_p]),
     "grx_bfs_count_visited": (None, [C.c_int, i32p, i32p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "grx_version": (C.c_char_p, []),

@@ -302,6 +302,7 @@ class BFSEnactor : public EnactorBase {
         };
         while (queue_length > 0) {
             const unsigned in_len = queue_length, in_edges = queue_edges;
+            bool binned_level = false;
             if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
 
             // ---- direction choice (Beamer's edge rule for down->up, the reference's vertex rule for up->down,
@@ -450,6 +451,7 @@ class BFSEnactor : public EnactorBase {
                     continue;  // (selector unchanged: no queue was written)
                 }
                 if (problem->binned_min_edges > 0 && static_cast<long long>(queue_edges) >= problem->binned_min_edges) {
+                    binned_level = true;
                     // ---- destination-binned level (oprtr/advance/binned.hpp): no claim atomics ----
                     int expand_grid = util::ResidentGrid(oprtr::advance::BinnedExpandKernel<BinnedPolicy, BFSProblem, BfsFunctor>,
                                                          BinnedPolicy::THREADS);
@@ -495,7 +497,7 @@ class BFSEnactor : public EnactorBase {
                 }
             } else if ((retval = work_progress.GetTail(static_cast<int>(iteration & 3), queue_length, queue_edges, stream)))
                 break;
-            if (INSTRUMENT) InstrumentCollect(in_len, in_edges, bottom_up ? 1 : 0);
+            if (INSTRUMENT) InstrumentCollect(in_len, in_edges, bottom_up ? 1 : (binned_level ? 7 : 0));
             if (DEBUG) std::printf("iteration %lld (%s): queue length %u, edges %u\n", iteration,
                                    bottom_up ? "bottom-up" : "top-down", queue_length, queue_edges);
         }

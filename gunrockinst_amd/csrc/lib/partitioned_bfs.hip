@@ -9,11 +9,23 @@
 //                local visited bitmap, label them, build the next local frontier;
 //     bottom-up: [all-gather of the per-rank frontier bitmaps, done by the caller] -> local sweep of unvisited owned
 //                vertices against the gathered bitmap (no id exchange at all).
-// The collectives live in gunrockinst_amd/multi_gpu.py (torch.distributed: RCCL on GPUs, gloo in CPU tests); this file
-// only exposes the local steps through the C ABI and never communicates.
+// Two ways to drive it:
+//   * grx_pbfs_search -- the whole level loop in C++ (Pbfs::Search): one host call per search, the exchange through a
+//     Transport.  RcclTransport issues ncclAllGather / grouped ncclSend+ncclRecv (all 7 xGMI links of a GPU at once) on the
+//     engine's own stream, so kernels and collectives are ordered by the stream and the host waits only where it needs a
+//     number: twice per top-down level (the P x P count matrix, the global frontier size), once per bottom-up level (the
+//     frontier sizes that ride in the trailing words of the gathered bitmaps).  RCCL is loaded with dlopen at the first
+//     use, so the library itself does not link against it.  CallbackTransport hands the same three exchanges to the
+//     caller (tests: several ranks sharing one GPU over gloo).
+//   * the step-wise entry points (grx_pbfs_advance_local, ...) with the collectives in the caller
+//     (gunrockinst_amd/multi_gpu.py): the executable model of the protocol that the CPU tests run over gloo.
+// With mark_pred the top-down exchange carries (local id, parent) pairs and the bottom-up sweep records the parent it
+// found, so the assembled predecessors are valid BFS parents on any number of ranks.
 #include <gunrock/gunrock_mi355x.h>
 
+#include <dlfcn.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include <gunrock/app/enactor_base.hpp>
@@ -27,17 +39,24 @@ using namespace gunrock;
 
 namespace {
 
+struct ncclUniqueIdBytes {  // layout of ncclUniqueId (rccl.h: char internal[128]), passed by value to ncclCommInitRank
+    char internal[128];
+};
+
 struct PbfsProblem {
     typedef int VertexId;
     typedef int SizeT;
     typedef int Value;
-    static constexpr bool MARK_PREDECESSORS = false;
+    static constexpr bool MARK_PREDECESSORS = true;  // (the bottom-up sweep records the parent it finds: one store per discovery)
     struct DataSlice {
         int *d_labels;              // local
-        int *d_preds;               // unused (MARK_PREDECESSORS = false)
+        int *d_preds;               // local: GLOBAL id of the parent (-1 source, -2 unreached)
         unsigned *d_visited_mask;   // local ids
         unsigned *d_sent_mask;      // GLOBAL ids: destinations this rank has already forwarded
         int iteration;
+        int *d_pred_global;         // mark_pred: GLOBAL ids -> the local source that forwarded it (as a global id), else nullptr
+        const int *d_recv_preds;    // mark_pred: parents that arrived with the ids being filtered, else nullptr
+        int parts, rank;
     };
 };
 
@@ -53,7 +72,10 @@ struct SendFunctor {
         const unsigned bit = 1u << (d & 31);
         return (atomicOr(p->d_sent_mask + (static_cast<unsigned>(d) >> 5), bit) & bit) == 0;
     }
-    static __device__ __forceinline__ void ApplyEdge(int, int, DataSlice *, int = 0, int = 0) {}
+    static __device__ __forceinline__ void ApplyEdge(int s, int d, DataSlice *p, int = 0, int = 0)
+    {
+        if (p->d_pred_global) p->d_pred_global[d] = s * p->parts + p->rank;  // (s is a LOCAL row: its global id)
+    }
 };
 
 // filter functor for received LOCAL ids: first arrival claims the vertex and labels it
@@ -66,9 +88,10 @@ struct ReceiveFunctor {
         if (*word & bit) return false;
         return (atomicOr(word, bit) & bit) == 0;
     }
-    static __device__ __forceinline__ void ApplyFilter(int node, DataSlice *p, int = 0, int = 0)
+    static __device__ __forceinline__ void ApplyFilter(int node, DataSlice *p, int = 0, int nid = 0)
     {
         p->d_labels[node] = p->iteration + 1;
+        if (p->d_recv_preds) p->d_preds[node] = p->d_recv_preds[nid];  // the pair that won the claim
     }
 };
 
@@ -110,6 +133,230 @@ __global__ void ScatterByOwnerKernel(const int *d_ids, int n, int parts, unsigne
     }
 }
 
+// ---- the same two bucketing steps for the in-library loop: the candidate count stays on the device (low word of a packed
+//      tail), the scatter computes the segment offsets itself, parents travel next to the ids ----
+__global__ void CountOwnersDeviceKernel(const int *d_ids, const unsigned long long *d_n, int parts, unsigned *d_counts)
+{
+    __shared__ unsigned s_count[64];
+    if (threadIdx.x < 64) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = static_cast<int>(util::TailCount(*d_n));
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        atomicAdd(&s_count[static_cast<unsigned>(d_ids[i]) % static_cast<unsigned>(parts)], 1u);
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < parts && s_count[threadIdx.x]) atomicAdd(d_counts + threadIdx.x, s_count[threadIdx.x]);
+}
+
+// d_counts[0..parts) = per-owner totals (complete), d_cursor[0..parts) = 0 on entry.
+// Two sweeps over the workgroup's share: count per owner in LDS, reserve each owner's run with ONE global atomic per
+// workgroup (a cursor is a hot address: ~88 atomics per microsecond -- one per wave cost 238 us for 1.3 M ids), then place.
+__global__ void ScatterByOwnerDeviceKernel(const int *d_ids, const unsigned long long *d_n, int parts, const unsigned *d_counts,
+                                           unsigned *d_cursor, int *d_out, const int *d_pred_global, int *d_out_preds)
+{
+    __shared__ unsigned s_count[64], s_base[64];
+    if (threadIdx.x < 64) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = static_cast<int>(util::TailCount(*d_n));
+    const int per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int begin = blockIdx.x * per_block;
+    const int end = begin + per_block < n ? begin + per_block : n;
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x)
+        atomicAdd(&s_count[static_cast<unsigned>(d_ids[i]) % static_cast<unsigned>(parts)], 1u);
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < parts) {
+        unsigned off = 0;  // start of this owner's segment = sum of the totals before it
+        for (int o = 0; o < static_cast<int>(threadIdx.x); ++o) off += d_counts[o];
+        const unsigned mine = s_count[threadIdx.x];
+        s_base[threadIdx.x] = off + (mine ? atomicAdd(d_cursor + threadIdx.x, mine) : 0u);
+        s_count[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const unsigned v = static_cast<unsigned>(d_ids[i]);
+        const unsigned o = v % static_cast<unsigned>(parts);
+        const unsigned at = s_base[o] + atomicAdd(&s_count[o], 1u);
+        d_out[at] = static_cast<int>(v / static_cast<unsigned>(parts));
+        if (d_out_preds) d_out_preds[at] = d_pred_global[v];
+    }
+}
+
+// a few device words -> pinned host memory + a sequence word (system-scope release): the host spins on the word instead of
+// paying a copy-engine transfer and a stream synchronisation (~25 us each) for every number it needs
+__global__ void MailKernel(const unsigned *d_src, int count, int stride, unsigned *h_box, unsigned long long *h_seq, unsigned long long seq)
+{
+    for (int i = threadIdx.x; i < count; i += blockDim.x) h_box[i] = d_src[static_cast<size_t>(i) * stride];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// everything Reset has to seed, in one launch (the step-wise Reset does it with seven tiny copies and two stream syncs)
+__global__ void PbfsSeedKernel(int src, int parts, int rank, const int *d_row_offsets, int *d_labels, int *d_preds,
+                               unsigned *d_visited, unsigned *d_sent, util::Frontier<int, int> queue0, unsigned long long *d_tail0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    d_sent[src >> 5] = 1u << (src & 31);  // every rank: the source is never forwarded
+    unsigned long long tail = 0ull;
+    if (src % parts == rank) {
+        const int local = src / parts;
+        const int begin = d_row_offsets[local], end = d_row_offsets[local + 1];
+        d_labels[local] = 0;
+        d_preds[local] = -1;
+        d_visited[local >> 5] = 1u << (local & 31);
+        queue0.v[0] = local;
+        queue0.row_start[0] = begin;
+        queue0.scan[0] = 0;
+        if (end > begin) tail = util::PackTail(1u, static_cast<unsigned>(end - begin));
+    }
+    *d_tail0 = tail;
+}
+
+// sum of the wide tail lines (the bottom-up sweep's per-workgroup find counts) -> one word, lines cleared
+__global__ void FoldWideKernel(unsigned long long *d_wide, unsigned *d_out, unsigned long long *d_tail_slot)
+{
+    const unsigned lane = threadIdx.x;
+    unsigned long long w = 0;
+    if (lane < 32) {
+        w = d_wide[lane * 16];
+        if (w) d_wide[lane * 16] = 0;
+    }
+    for (int o = 16; o; o >>= 1) w += __shfl_xor(w, o, 64);
+    if (lane == 0) {
+        if (d_tail_slot) {
+            w += *d_tail_slot;
+            *d_tail_slot = 0ull;
+        }
+        *d_out = util::TailCount(w);
+    }
+}
+
+// ---- the exchange: what a level needs from the other ranks ----
+struct Transport {
+    virtual ~Transport() {}
+    // every rank contributes `words` 32-bit words; d_recv receives parts * words (rank order).  Enqueued on `stream` or
+    // complete on return; the caller synchronises the stream before it reads the result on the host.
+    virtual int AllGather(const unsigned *d_send, unsigned *d_recv, size_t words, hipStream_t stream) = 0;
+    // 32-bit words: segment p of d_send goes to rank p, segment p of d_recv comes from rank p
+    virtual int AllToAllV(const int *d_send, const size_t *send_counts, const size_t *send_offsets, int *d_recv,
+                          const size_t *recv_counts, const size_t *recv_offsets, hipStream_t stream) = 0;
+    virtual const char *Name() const = 0;
+};
+
+// RCCL through dlopen: the library does not link against librccl; torch's copy is reused when it is already loaded
+struct RcclApi {
+    typedef int (*GetUniqueId_t)(void *);
+    typedef int (*CommInitRank_t)(void **, int, ncclUniqueIdBytes, int);
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, ncclUniqueIdBytes id, int rank) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+
+    static RcclApi &Get()
+    {
+        static RcclApi api;
+        return api;
+    }
+    bool Load()
+    {
+        if (handle) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names)
+            if ((handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!handle) {
+            std::fprintf(stderr, "gunrock: cannot load RCCL (%s)\n", dlerror());
+            return false;
+        }
+        bool ok = true;
+        auto sym = [&](const char *nm) {
+            void *p = dlsym(handle, nm);
+            if (!p) {
+                std::fprintf(stderr, "gunrock: RCCL symbol %s missing\n", nm);
+                ok = false;
+            }
+            return p;
+        };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) handle = nullptr;
+        return ok;
+    }
+};
+
+struct RcclTransport : Transport {
+    void *comm = nullptr;
+    int parts = 1, rank = 0;
+    static constexpr int kInt32 = 2;  // ncclInt32 (rccl.h ncclDataType_t)
+    int Check(int rc, const char *what)
+    {
+        if (rc != 0) std::fprintf(stderr, "gunrock: RCCL %s failed: %s\n", what, RcclApi::Get().GetErrorString ? RcclApi::Get().GetErrorString(rc) : "?");
+        return rc;
+    }
+    int Init(int parts_, int rank_, const char id[128])
+    {
+        RcclApi &api = RcclApi::Get();
+        if (!api.Load()) return -1;
+        parts = parts_;
+        rank = rank_;
+        ncclUniqueIdBytes uid;
+        std::memcpy(uid.internal, id, 128);
+        return Check(api.CommInitRank(&comm, parts, uid, rank), "ncclCommInitRank");
+    }
+    ~RcclTransport() override
+    {
+        if (comm) RcclApi::Get().CommDestroy(comm);
+    }
+    int AllGather(const unsigned *d_send, unsigned *d_recv, size_t words, hipStream_t stream) override
+    {
+        return Check(RcclApi::Get().AllGather(d_send, d_recv, words, kInt32, comm, stream), "ncclAllGather");
+    }
+    int AllToAllV(const int *d_send, const size_t *sc, const size_t *so, int *d_recv, const size_t *rc, const size_t *ro,
+                  hipStream_t stream) override
+    {
+        RcclApi &api = RcclApi::Get();
+        int err = api.GroupStart();
+        for (int p = 0; p < parts && !err; ++p) {  // all peers at once: xGMI is point-to-point, every link carries its own pair
+            if (sc[p]) err = api.Send(d_send + so[p], sc[p], kInt32, p, comm, stream);
+            if (!err && rc[p]) err = api.Recv(d_recv + ro[p], rc[p], kInt32, p, comm, stream);
+        }
+        const int end = api.GroupEnd();
+        return Check(err ? err : end, "ncclSend/ncclRecv group");
+    }
+    const char *Name() const override { return "rccl"; }
+};
+
+// the caller performs the exchange (synchronously); used by tests that run several ranks on one GPU over gloo
+struct CallbackTransport : Transport {
+    void *ctx = nullptr;
+    grx_all_gather_fn gather = nullptr;
+    grx_all_to_all_v_fn a2a = nullptr;
+    int AllGather(const unsigned *d_send, unsigned *d_recv, size_t words, hipStream_t stream) override
+    {
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        return gather(ctx, d_send, d_recv, words);
+    }
+    int AllToAllV(const int *d_send, const size_t *sc, const size_t *so, int *d_recv, const size_t *rc, const size_t *ro,
+                  hipStream_t stream) override
+    {
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        return a2a(ctx, d_send, sc, so, d_recv, rc, ro);
+    }
+    const char *Name() const override { return "callbacks"; }
+};
+
 struct Pbfs : app::EnactorBase {
     int parts = 1, rank = 0;
     int n_global = 0, n_local = 0, n_local_max = 0, m_local = 0;
@@ -125,6 +372,21 @@ struct Pbfs : app::EnactorBase {
     int selector = 0, cur_mask = 0;
     unsigned frontier_len = 0, frontier_edges = 0;
     int level = 0;
+    // ---- in-library level loop (Search) ----
+    Transport *transport = nullptr;
+    bool mark_pred = false;
+    double alpha = 10.0;                 // top-down -> bottom-up when global frontier edges * alpha > unexplored edges
+    long long m_global = -1;             // sum of the ranks' edge counts (learned through the transport)
+    int *d_recv = nullptr;               // received local ids, then (mark_pred) received parents behind them
+    int recv_capacity = 0;
+    int *d_send_preds = nullptr;
+    unsigned *d_small = nullptr;         // [0, 64): counts to send; [64, 128): cursors; [128, 128 + 64 * 64): gathered matrices
+    unsigned *h_small = nullptr;         // pinned + mapped mirror of the gathered part; word [64 * 64] onwards: the mail sequence
+    unsigned long long mail_seq = 0;
+    unsigned *d_visited_before = nullptr;  // local visited bitmap as it was before the last top-down level
+    unsigned *d_gathered = nullptr;      // parts x (bitmap words + 2)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<size_t> sc, so, rc, ro;
 
     Pbfs() : app::EnactorBase(app::VERTEX_FRONTIERS, false) {}
 
@@ -142,7 +404,11 @@ struct Pbfs : app::EnactorBase {
         GR_CHECK(hipMalloc(&ds.d_labels, sizeof(int) * nl), "Pbfs hipMalloc failed");
         GR_CHECK(hipMalloc(&ds.d_visited_mask, sizeof(unsigned) * (MaskWords(n_local) + 2)), "Pbfs hipMalloc failed");
         GR_CHECK(hipMalloc(&ds.d_sent_mask, sizeof(unsigned) * (MaskWords(n_global) + 2)), "Pbfs hipMalloc failed");
-        ds.d_preds = nullptr;
+        GR_CHECK(hipMalloc(&ds.d_preds, sizeof(int) * nl), "Pbfs hipMalloc failed");
+        ds.d_pred_global = nullptr;
+        ds.d_recv_preds = nullptr;
+        ds.parts = parts;
+        ds.rank = rank;
         for (int i = 0; i < 2; ++i) {
             GR_CHECK(hipMalloc(&d_frontier_mask[i], sizeof(unsigned) * (MaskWords(n_local_max) + 2)), "Pbfs hipMalloc failed");
             const size_t cap = nl + 1024;
@@ -170,7 +436,18 @@ struct Pbfs : app::EnactorBase {
 
     ~Pbfs() override
     {
+        delete transport;
         if (ds.d_labels) hipFree(ds.d_labels);
+        if (ds.d_preds) hipFree(ds.d_preds);
+        if (ds.d_pred_global) hipFree(ds.d_pred_global);
+        if (d_recv) hipFree(d_recv);
+        if (d_send_preds) hipFree(d_send_preds);
+        if (d_small) hipFree(d_small);
+        if (h_small) hipHostFree(h_small);
+        if (d_gathered) hipFree(d_gathered);
+        if (d_visited_before) hipFree(d_visited_before);
+        if (ev_start) hipEventDestroy(ev_start);
+        if (ev_stop) hipEventDestroy(ev_stop);
         if (ds.d_visited_mask) hipFree(ds.d_visited_mask);
         if (ds.d_sent_mask) hipFree(ds.d_sent_mask);
         for (int i = 0; i < 2; ++i) {
@@ -191,6 +468,7 @@ struct Pbfs : app::EnactorBase {
     {
         hipError_t retval = hipSuccess;
         util::Memset(ds.d_labels, -1, n_local, stream);
+        util::Memset(ds.d_preds, -2, n_local, stream);
         util::Memset(ds.d_visited_mask, 0u, MaskWords(n_local) + 2, stream);
         util::Memset(ds.d_sent_mask, 0u, MaskWords(n_global) + 2, stream);
         for (int i = 0; i < 2; ++i) util::Memset(d_frontier_mask[i], 0u, MaskWords(n_local_max) + 2, stream);
@@ -207,7 +485,9 @@ struct Pbfs : app::EnactorBase {
                 GR_CHECK(hipStreamSynchronize(stream), "Pbfs seed failed");
                 const int zero = 0;
                 const unsigned lbit = 1u << (local & 31);
+                const int minus_one = -1;
                 GR_CHECK(hipMemcpyAsync(ds.d_labels + local, &zero, sizeof(int), hipMemcpyHostToDevice, stream), "Pbfs seed failed");
+                GR_CHECK(hipMemcpyAsync(ds.d_preds + local, &minus_one, sizeof(int), hipMemcpyHostToDevice, stream), "Pbfs seed failed");
                 GR_CHECK(hipMemcpyAsync(ds.d_visited_mask + (local >> 5), &lbit, sizeof(unsigned), hipMemcpyHostToDevice, stream), "Pbfs seed failed");
                 GR_CHECK(hipMemcpyAsync(queues[0].v, &local, sizeof(int), hipMemcpyHostToDevice, stream), "Pbfs seed failed");
                 GR_CHECK(hipMemcpyAsync(queues[0].row_start, &row[0], sizeof(int), hipMemcpyHostToDevice, stream), "Pbfs seed failed");
@@ -357,6 +637,234 @@ struct Pbfs : app::EnactorBase {
         *edges = frontier_edges;
         return retval;
     }
+
+    // ================================================================================================================
+    // The level loop inside the library
+    // ================================================================================================================
+    hipError_t PrepareSearch()
+    {
+        hipError_t retval = hipSuccess;
+        if (!transport) return hipErrorNotInitialized;
+        if (!d_small) {
+            GR_CHECK(hipMalloc(&d_small, sizeof(unsigned) * (128 + 64 * 64)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipHostMalloc(&h_small, sizeof(unsigned) * (64 * 64 + 4), hipHostMallocMapped), "Pbfs hipHostMalloc failed");
+            std::memset(h_small, 0, sizeof(unsigned) * (64 * 64 + 4));
+            GR_CHECK(hipMalloc(&d_visited_before, sizeof(unsigned) * (MaskWords(n_local) + 2)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_gathered, sizeof(unsigned) * static_cast<size_t>(parts) * (MaskWords(n_local_max) + 2)), "Pbfs hipMalloc failed");
+            // a rank forwards every vertex at most once per search, so at most parts * (my vertices) ids arrive per search
+            recv_capacity = parts * n_local_max + 1024;
+            GR_CHECK(hipMalloc(&d_recv, sizeof(int) * 2 * static_cast<size_t>(recv_capacity)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipEventCreate(&ev_start), "Pbfs hipEventCreate failed");
+            GR_CHECK(hipEventCreate(&ev_stop), "Pbfs hipEventCreate failed");
+            sc.assign(parts, 0); so.assign(parts, 0); rc.assign(parts, 0); ro.assign(parts, 0);
+        }
+        if (mark_pred && !ds.d_pred_global) {
+            GR_CHECK(hipMalloc(&ds.d_pred_global, sizeof(int) * static_cast<size_t>(n_global + 1)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_send_preds, sizeof(int) * static_cast<size_t>(candidate_capacity)), "Pbfs hipMalloc failed");
+        }
+        if (m_global < 0) {  // sum of the local edge counts (two 31-bit halves per rank through the word all-gather)
+            const unsigned halves[2] = {static_cast<unsigned>(m_local) & 0xFFFFu, static_cast<unsigned>(m_local) >> 16};
+            GR_CHECK(hipMemcpyAsync(d_small, halves, sizeof(halves), hipMemcpyHostToDevice, stream), "Pbfs copy failed");
+            if (transport->AllGather(d_small, d_small + 128, 2, stream)) return hipErrorUnknown;
+            GR_CHECK(hipMemcpyAsync(h_small, d_small + 128, sizeof(unsigned) * 2 * parts, hipMemcpyDeviceToHost, stream), "Pbfs copy failed");
+            GR_CHECK(hipStreamSynchronize(stream), "Pbfs sync failed");
+            m_global = 0;
+            for (int p = 0; p < parts; ++p) m_global += static_cast<long long>(h_small[2 * p]) + (static_cast<long long>(h_small[2 * p + 1]) << 16);
+        }
+        return retval;
+    }
+
+    // `count` device words, `stride` words apart, to h_small[0..count): one tiny kernel + a host spin on its sequence word
+    hipError_t Mail(const unsigned *d_src, int count, int stride)
+    {
+        hipError_t retval = hipSuccess;
+        unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(h_small + 64 * 64);
+        ++mail_seq;
+        hipLaunchKernelGGL(MailKernel, dim3(1), dim3(64), 0, stream, d_src, count, stride, h_small, h_seq, mail_seq);
+        GR_CHECK(hipGetLastError(), "MailKernel launch failed");
+        unsigned spins = 0;
+        while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != mail_seq) {
+            if ((++spins & 0x3FFu) == 0) {
+                const hipError_t rc = hipStreamQuery(stream);
+                if (rc == hipSuccess) {
+                    if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == mail_seq) break;
+                    continue;
+                }
+                if (rc != hipErrorNotReady) return util::GRError(rc, "Pbfs Mail: stream failed", __FILE__, __LINE__);
+            }
+        }
+        return retval;
+    }
+
+    // all-gather of 2 words per rank (this rank's packed tail at `d_tail_word`) -> global frontier (vertices, edges)
+    hipError_t GlobalTail(const unsigned long long *d_tail_word, unsigned long long &glen, unsigned long long &gedges, unsigned &my_len,
+                          unsigned &my_edges)
+    {
+        hipError_t retval = hipSuccess;
+        if (transport->AllGather(reinterpret_cast<const unsigned *>(d_tail_word), d_small + 128, 2, stream)) return hipErrorUnknown;
+        if ((retval = Mail(d_small + 128, 2 * parts, 1))) return retval;
+        glen = 0; gedges = 0;
+        for (int p = 0; p < parts; ++p) {  // PackTail: low word = vertices, high word = edges
+            glen += h_small[2 * p];
+            gedges += h_small[2 * p + 1];
+        }
+        my_len = h_small[2 * rank];
+        my_edges = h_small[2 * rank + 1];
+        return retval;
+    }
+
+    // One search, every level inside this call.  levels_out = BSP levels executed (the reference's search_depth).
+    hipError_t Search(int src, bool direction_optimizing, int *levels_out, float *elapsed_ms)
+    {
+        hipError_t retval = hipSuccess;
+        if ((retval = PrepareSearch())) return retval;
+        if (src < 0 || src >= n_global) return hipErrorInvalidValue;
+        GR_CHECK(hipEventRecord(ev_start, stream), "Pbfs hipEventRecord failed");
+        // ---- reset + seed (the reference times Reset outside Enact; here it is inside the call and the bench says so) ----
+        util::Memset(ds.d_labels, -1, n_local, stream);
+        util::Memset(ds.d_preds, -2, n_local, stream);
+        util::Memset(ds.d_visited_mask, 0u, MaskWords(n_local) + 2, stream);
+        util::Memset(ds.d_sent_mask, 0u, MaskWords(n_global) + 2, stream);
+        if ((retval = work_progress.Reset(stream))) return retval;
+        hipLaunchKernelGGL(PbfsSeedKernel, dim3(1), dim3(64), 0, stream, src, parts, rank, d_row_offsets, ds.d_labels, ds.d_preds,
+                           ds.d_visited_mask, ds.d_sent_mask, queues[0], work_progress.d_tail + 0);
+        GR_CHECK(hipGetLastError(), "PbfsSeedKernel launch failed");
+        selector = 0; cur_mask = 0; level = 0;
+        unsigned long long glen = 0, gedges = 0;
+        if ((retval = GlobalTail(work_progress.d_tail + 0, glen, gedges, frontier_len, frontier_edges))) return retval;
+        long long unexplored = m_global;
+        int levels = 0;
+        const int wpr = MaskWords(n_local_max);  // bitmap words per rank; two trailing words carry the frontier size
+        const int wpr_local = MaskWords(n_local);
+        GR_CHECK(hipMemsetAsync(d_visited_before, 0, sizeof(unsigned) * (wpr_local + 2), stream), "Pbfs memset failed");
+        while (glen > 0) {
+            if (direction_optimizing && static_cast<double>(gedges) * alpha > static_cast<double>(unexplored)) {
+                // ---- bottom-up to the end: ONE collective per level, the all-gather of the frontier bitmaps ----
+                // the local frontier = what the last top-down level added to the local visited bitmap (zero-degree finds
+                // included: nobody can adopt them as parent); at level 0 the snapshot is the empty bitmap
+                GR_CHECK(hipMemsetAsync(work_progress.d_tail + 1, 0, sizeof(unsigned long long), stream), "Pbfs clear tail failed");
+                GR_CHECK(hipMemsetAsync(d_frontier_mask[cur_mask] + wpr, 0, sizeof(unsigned) * 2, stream), "Pbfs memset failed");
+                hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(cu_count * 2), dim3(256), 0, stream,
+                                   reinterpret_cast<const unsigned long long *>(ds.d_visited_mask),
+                                   reinterpret_cast<const unsigned long long *>(d_visited_before),
+                                   reinterpret_cast<unsigned long long *>(d_frontier_mask[cur_mask]), static_cast<long long>(wpr_local / 2));
+                GR_CHECK(hipGetLastError(), "BitmapDiffKernel launch failed");
+                if (wpr > wpr_local)
+                    GR_CHECK(hipMemsetAsync(d_frontier_mask[cur_mask] + wpr_local, 0, sizeof(unsigned) * (wpr - wpr_local), stream), "Pbfs memset failed");
+                GR_CHECK(hipMemcpyAsync(d_frontier_mask[cur_mask] + wpr, &frontier_len, sizeof(unsigned), hipMemcpyHostToDevice, stream),
+                         "Pbfs copy failed");
+                for (;;) {
+                    if (transport->AllGather(d_frontier_mask[cur_mask], d_gathered, static_cast<size_t>(wpr + 2), stream)) return hipErrorUnknown;
+                    if ((retval = Mail(d_gathered + wpr, parts, wpr + 2))) return retval;
+                    unsigned long long total = 0;
+                    for (int p = 0; p < parts; ++p) total += h_small[p];
+                    if (total == 0) break;
+                    oprtr::advance::BottomUpArgs<int, int> b;
+                    b.nodes = n_local;
+                    b.d_inv_row_offsets = d_row_offsets;
+                    b.d_inv_column_indices = d_col_indices;
+                    b.d_inv_heads = d_heads;
+                    b.d_frontier_out = reinterpret_cast<unsigned long long *>(d_frontier_mask[cur_mask ^ 1]);
+                    b.d_visited = reinterpret_cast<unsigned long long *>(ds.d_visited_mask);
+                    b.d_tail_out = work_progress.d_tail + 1;
+                    b.d_tail_clear = nullptr;
+                    b.d_wide = work_progress.d_wide;
+                    ds.iteration = level;
+                    oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(wpr + 2)};
+                    const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
+                    long long grid = (bu_steps + 3) / 4;
+                    const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
+                    if (grid > cap) grid = cap;
+                    if (grid < 1) grid = 1;
+                    hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
+                                       dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
+                    GR_CHECK(hipGetLastError(), "BottomUpKernel launch failed");
+                    // this level's finds = the next frontier's size: folded on the device into the bitmap's trailing word
+                    hipLaunchKernelGGL(FoldWideKernel, dim3(1), dim3(64), 0, stream, work_progress.d_wide, d_frontier_mask[cur_mask ^ 1] + wpr,
+                                       work_progress.d_tail + 1);
+                    GR_CHECK(hipGetLastError(), "FoldWideKernel launch failed");
+                    cur_mask ^= 1;
+                    ++level;
+                    ++levels;
+                }
+                break;
+            }
+            // ---- top-down level: advance -> bucket by owner -> counts all-gather -> ids (+ parents) all-to-all -> filter ----
+            unexplored -= static_cast<long long>(gedges);
+            GR_CHECK(hipMemcpyAsync(d_visited_before, ds.d_visited_mask, sizeof(unsigned) * (wpr_local + 2), hipMemcpyDeviceToDevice, stream),
+                     "Pbfs visited snapshot failed");
+            GR_CHECK(hipMemsetAsync(work_progress.d_tail, 0, sizeof(unsigned long long) * 2, stream), "Pbfs clear tail failed");
+            GR_CHECK(hipMemsetAsync(d_small, 0, sizeof(unsigned) * 128, stream), "Pbfs clear counts failed");
+            if (frontier_len > 0) {
+                oprtr::advance::AdvanceArgs<int, int> args;
+                args.in = queues[selector];
+                args.out = util::Frontier<int, int>();
+                args.out.v = d_candidates;
+                args.out.capacity = candidate_capacity;
+                args.in_len = static_cast<int>(frontier_len);
+                args.in_edges = static_cast<int>(frontier_edges);
+                args.d_row_offsets = d_row_offsets;
+                args.d_column_indices = d_col_indices;
+                args.d_tail_out = work_progress.d_tail + 0;
+                args.d_tail_clear = nullptr;
+                args.d_overflow = work_progress.d_overflow;
+                ds.iteration = level;
+                typedef oprtr::advance::KernelPolicy<256, 8, 3, oprtr::advance::LB> Policy;
+                if ((retval = oprtr::advance::LaunchKernel<Policy, PbfsProblem, SendFunctor, false>(args, ds, 0, stream))) return retval;
+                // (the candidate count stays on the device: the bucketing kernels read it there)
+                const int grid = cu_count * 4;
+                hipLaunchKernelGGL(CountOwnersDeviceKernel, dim3(grid), dim3(256), 0, stream, d_candidates, work_progress.d_tail + 0, parts, d_small);
+                GR_CHECK(hipGetLastError(), "CountOwnersDeviceKernel launch failed");
+                hipLaunchKernelGGL(ScatterByOwnerDeviceKernel, dim3(grid), dim3(256), 0, stream, d_candidates, work_progress.d_tail + 0, parts,
+                                   d_small, d_small + 64, d_send, mark_pred ? ds.d_pred_global : nullptr, mark_pred ? d_send_preds : nullptr);
+                GR_CHECK(hipGetLastError(), "ScatterByOwnerDeviceKernel launch failed");
+            }
+            // P x P count matrix: row p = what rank p sends to everybody
+            if (transport->AllGather(d_small, d_small + 128, static_cast<size_t>(parts), stream)) return hipErrorUnknown;
+            if ((retval = Mail(d_small + 128, parts * parts, 1))) return retval;
+            size_t send_total = 0, recv_total = 0;
+            for (int p = 0; p < parts; ++p) {
+                sc[p] = h_small[rank * parts + p];
+                so[p] = send_total;
+                send_total += sc[p];
+                rc[p] = h_small[p * parts + rank];
+                ro[p] = recv_total;
+                recv_total += rc[p];
+            }
+            if (recv_total > static_cast<size_t>(recv_capacity)) return util::GRError(hipErrorInvalidConfiguration, "Pbfs receive buffer overflow", __FILE__, __LINE__);
+            if (transport->AllToAllV(d_send, sc.data(), so.data(), d_recv, rc.data(), ro.data(), stream)) return hipErrorUnknown;
+            if (mark_pred && transport->AllToAllV(d_send_preds, sc.data(), so.data(), d_recv + recv_capacity, rc.data(), ro.data(), stream))
+                return hipErrorUnknown;
+            if (recv_total > 0) {
+                oprtr::filter::FilterArgs<int, int> f;
+                f.d_in = d_recv;
+                f.num_elements = static_cast<int>(recv_total);
+                f.out = queues[selector ^ 1];
+                f.d_tail_out = work_progress.d_tail + 1;
+                f.d_tail_clear = nullptr;
+                f.d_overflow = work_progress.d_overflow;
+                f.d_row_offsets = d_row_offsets;
+                ds.iteration = level;
+                ds.d_recv_preds = mark_pred ? d_recv + recv_capacity : nullptr;
+                typedef oprtr::filter::KernelPolicy<256, 4, 8> Policy;
+                retval = oprtr::filter::LaunchKernel<Policy, PbfsProblem, ReceiveFunctor, true>(f, ds, cu_count * 8, stream);
+                ds.d_recv_preds = nullptr;
+                if (retval) return retval;
+            }
+            selector ^= 1;
+            ++level;
+            ++levels;
+            if ((retval = GlobalTail(work_progress.d_tail + 1, glen, gedges, frontier_len, frontier_edges))) return retval;
+        }
+        GR_CHECK(hipEventRecord(ev_stop, stream), "Pbfs hipEventRecord failed");
+        GR_CHECK(hipEventSynchronize(ev_stop), "Pbfs hipEventSynchronize failed");
+        if (elapsed_ms) GR_CHECK(hipEventElapsedTime(elapsed_ms, ev_start, ev_stop), "Pbfs hipEventElapsedTime failed");
+        if (levels_out) *levels_out = levels;
+        int overflow = 0;
+        GR_CHECK(hipMemcpy(&overflow, work_progress.d_overflow, sizeof(int), hipMemcpyDeviceToHost), "Pbfs read overflow failed");
+        if (overflow) return util::GRError(hipErrorInvalidConfiguration, "Frontier queue overflow. Please increase queue-sizing factor.", __FILE__, __LINE__);
+        return retval;
+    }
 };
 
 }  // namespace
@@ -432,6 +940,67 @@ int grx_pbfs_labels(grx_pbfs *p, int **d_labels)
     if (!p || !d_labels) return -1;
     *d_labels = p->impl.ds.d_labels;
     return 0;
+}
+
+int grx_pbfs_preds(grx_pbfs *p, int **d_preds)
+{
+    if (!p || !d_preds) return -1;
+    *d_preds = p->impl.ds.d_preds;
+    return 0;
+}
+
+int grx_rccl_unique_id(char id[128])
+{
+    if (!id) return -1;
+    RcclApi &api = RcclApi::Get();
+    if (!api.Load()) return -2;
+    ncclUniqueIdBytes uid;
+    std::memset(&uid, 0, sizeof(uid));
+    const int rc = api.GetUniqueId(&uid);
+    std::memcpy(id, uid.internal, 128);
+    return rc;
+}
+
+int grx_pbfs_comm_init_rccl(grx_pbfs *p, const char id[128])
+{
+    if (!p || !id) return -1;
+    RcclTransport *t = new RcclTransport();
+    const int rc = t->Init(p->impl.parts, p->impl.rank, id);
+    if (rc) {
+        delete t;
+        return rc;
+    }
+    delete p->impl.transport;
+    p->impl.transport = t;
+    p->impl.m_global = -1;
+    return 0;
+}
+
+int grx_pbfs_set_transport(grx_pbfs *p, void *ctx, grx_all_gather_fn all_gather, grx_all_to_all_v_fn all_to_all_v)
+{
+    if (!p || !all_gather || !all_to_all_v) return -1;
+    CallbackTransport *t = new CallbackTransport();
+    t->ctx = ctx;
+    t->gather = all_gather;
+    t->a2a = all_to_all_v;
+    delete p->impl.transport;
+    p->impl.transport = t;
+    p->impl.m_global = -1;
+    return 0;
+}
+
+int grx_pbfs_set_options(grx_pbfs *p, int mark_pred, float alpha)
+{
+    if (!p) return -1;
+    p->impl.mark_pred = mark_pred != 0;
+    if (alpha > 0) p->impl.alpha = alpha;
+    return 0;
+}
+
+int grx_pbfs_search(grx_pbfs *p, int src, int direction_optimizing, int *levels, float *elapsed_ms)
+{
+    if (!p) return -1;
+    return static_cast<int>(p->impl.Search(src, direction_optimizing != 0, levels, elapsed_ms));
 }
 
 void grx_pbfs_destroy(grx_pbfs *p) { delete p; }

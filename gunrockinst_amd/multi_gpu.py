@@ -298,6 +298,84 @@ class HipEngine:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the level loop INSIDE the library (grx_pbfs_search): one call per search, RCCL issued from C++ on the engine's stream
+# ------------------------------------------------------------------------------------------------------------------
+_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p,
+                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+
+
+class LibraryBfs:
+    """Vertex-partitioned BFS with the level loop in C++ (csrc/lib/partitioned_bfs.hip, Pbfs::Search).
+
+    transport = "rccl": the library creates its own RCCL communicator (the 128-byte id travels over torch.distributed
+    once, at construction) and issues every collective itself -- nothing of a search runs in Python.
+    transport = "callbacks": the same C++ loop, the three exchanges handed back to torch.distributed (gloo, host-staged);
+    for tests that run several ranks on one GPU, where RCCL cannot be used."""
+
+    def __init__(self, engine, comm, transport="rccl", mark_pred=False, alpha=0.0):
+        self.engine, self.comm = engine, comm
+        self.lib = engine.lib
+        self._h = engine._h
+        if transport == "rccl":
+            buf = C.create_string_buffer(128)
+            if comm.rank == 0:
+                HipEngine._check(self.lib.grx_rccl_unique_id(buf), "grx_rccl_unique_id")
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=comm.group)
+            HipEngine._check(self.lib.grx_pbfs_comm_init_rccl(self._h, box[0]), "grx_pbfs_comm_init_rccl")
+        else:
+            self._gather_cb = _GATHER_FN(self._all_gather)
+            self._a2a_cb = _A2A_FN(self._all_to_all_v)
+            HipEngine._check(self.lib.grx_pbfs_set_transport(self._h, None, C.cast(self._gather_cb, C.c_void_p),
+                                                             C.cast(self._a2a_cb, C.c_void_p)), "grx_pbfs_set_transport")
+        HipEngine._check(self.lib.grx_pbfs_set_options(self._h, int(bool(mark_pred)), float(alpha)), "grx_pbfs_set_options")
+        self.transport = transport
+
+    # ---- callback transport: device pointers in, torch.distributed (host-staged when the backend is gloo) in between ----
+    def _tensor(self, ptr, words):
+        return self.engine._dg.as_tensor(ptr, int(words), device=self.engine.device)
+
+    def _all_gather(self, ctx, d_send, d_recv, words):
+        try:
+            out = self.comm.all_gather(self._tensor(d_send, words))
+            self._tensor(d_recv, words * self.comm.world).copy_(out)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as exc:  # a Python exception must not unwind through the C frame
+            print("gunrockinst_amd: all_gather callback failed:", exc, flush=True)
+            return 1
+
+    def _all_to_all_v(self, ctx, d_send, sc, so, d_recv, rc, ro):
+        try:
+            world = self.comm.world
+            scl = [int(sc[p]) for p in range(world)]
+            rcl = [int(rc[p]) for p in range(world)]
+            # segments are contiguous in rank order on both sides (offsets = prefix sums of the counts)
+            send = self._tensor(d_send, sum(scl)) if sum(scl) else torch.empty(0, dtype=torch.int32, device=self.engine.device)
+            recv = self.comm.all_to_all_v(send, scl, rcl)
+            if sum(rcl):
+                self._tensor(d_recv, sum(rcl)).copy_(recv)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as exc:
+            print("gunrockinst_amd: all_to_all_v callback failed:", exc, flush=True)
+            return 1
+
+    def search(self, src, direction_optimizing=True):
+        """Returns (levels, elapsed_ms on this rank)."""
+        levels, ms = C.c_int(), C.c_float()
+        HipEngine._check(self.lib.grx_pbfs_search(self._h, int(src), int(bool(direction_optimizing)), C.byref(levels), C.byref(ms)),
+                         "grx_pbfs_search")
+        return int(levels.value), float(ms.value)
+
+    def preds(self):
+        ptr = C.c_void_p()
+        HipEngine._check(self.lib.grx_pbfs_preds(self._h, C.byref(ptr)), "grx_pbfs_preds")
+        return self.engine._dg.as_tensor(ptr.value, self.engine.n_local, device=self.engine.device).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # partitioned graph construction on the device
 # ------------------------------------------------------------------------------------------------------------------
 def partition_rmat_device(scale, edge_factor, seed, rank, parts, device="cuda"):
@@ -368,14 +446,20 @@ def bench(args, rank, world, local_rank):
     sources = [src0] + [v for v, d in zip(picks, degs) if d > 0][:64]
 
     eng = HipEngine(n, world, rank, ro, ci, local_rank)
-    bfs = PartitionedBfs(eng, comm, n, m_global)
+    # The level loop runs inside the library (Pbfs::Search): RCCL issued from C++ on the engine's stream.  With
+    # GUNROCK_DIST_BACKEND=gloo (several ranks rehearsing on one GPU) the same loop hands its exchanges back to gloo.
+    # GUNROCK_PBFS_LOOP=python: the step-wise model of the protocol (PartitionedBfs), collectives through torch.distributed.
+    python_loop = os.environ.get("GUNROCK_PBFS_LOOP") == "python"
+    if python_loop:
+        bfs = PartitionedBfs(eng, comm, n, m_global)
 
-    # top-down levels exchange ids (all-to-all); from the first bottom-up level on, one all-gather per level to the end.
-    # GUNROCK_PBFS_SCHEDULE=exchange: the direction rules in both directions, an all-reduce per level (the first form).
-    gather = os.environ.get("GUNROCK_PBFS_SCHEDULE", "sticky") != "exchange"
+        def search(s):
+            return bfs.run(s, True, sticky_bottom_up=True)
+    else:
+        bfs = LibraryBfs(eng, comm, transport="callbacks" if comm.host_staged else "rccl", mark_pred=False)
 
-    def search(s):
-        return bfs.run(s, True, sticky_bottom_up=gather)
+        def search(s):
+            return bfs.search(s, True)[0]
     for k in range(args.warmup):
         search(sources[k % len(sources)])
     torch.cuda.synchronize()
@@ -400,20 +484,17 @@ def bench(args, rank, world, local_rank):
     edges_total = sum(per_src[s][1] for s in used)
     nodes_total = sum(per_src[s][0] for s in used)
 
-    # parity: rank 0 runs the single-GPU engine on the whole graph for the first source and compares all labels
+    # parity: rank 0 rebuilds the whole graph, runs the CPU oracle's serial BFS from the first source and compares every label
     search(sources[0])
     full = assemble_labels(comm, eng.labels(), n)
     parity = None
-    if rank == 0:
-        import gunrockinst_amd as ga
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import gr_oracle as o
         gro, gci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
-        p = ga.BfsProblem(False, True, False, local_rank).init_device(n, int(gci.shape[0]), gro.data_ptr(), gci.data_ptr())
-        p.set_inverse_graph()
-        p.reset(sources[0])
-        p.enact(sources[0], traversal_mode=2)
-        single, _ = p.extract()
-        p.close()
-        parity = bool((single == full).all()) and int(gci.shape[0]) == m_global
+        h_ro, h_ci = devgraph.to_host_csr(gro, gci)
+        del gro, gci
+        ref, _, _ = o.bfs(o.Csr(n, h_ro, h_ci), sources[0])
+        parity = bool((ref == full).all()) and int(h_ci.shape[0]) == m_global
     bfs_runs = args.warmup + args.steps + len(set(used)) + 1
     eng.close()
 
@@ -426,13 +507,14 @@ def bench(args, rank, world, local_rank):
         "config": {"workload": "BFS direction-optimizing, R-MAT scale-%d (%d pairs/vertex mirrored, seed 0x%x) "
                                "vertex-partitioned over %d GPUs (owner = v mod %d), %s: "
                                "n=%d, m=%d" % (args.scale, args.edge_factor, args.seed, world, world,
-                                               "top-down levels: RCCL all-to-all of ids; from the first bottom-up level on one all-gather of the frontier bitmaps per level (sizes ride along)" if gather
-                                               else "RCCL all-to-all / all-gather + all-reduce per level", n, m_global),
+                                               "level loop in C++ inside the library; top-down levels: RCCL count all-gather + grouped send/recv of ids; from the first "
+                                               "bottom-up level on one all-gather of the frontier bitmaps per level (sizes ride along)" if not python_loop
+                                               else "level loop in Python over torch.distributed (protocol model)", n, m_global),
                    "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend},
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
-        "parity_vs_single_gpu": parity,
+        "parity_vs_oracle": parity,
         "level_loop_profile_ms_per_step": ({k: round(v * 1e3 / max(bfs_runs, 1), 4) for k, v in sorted(bfs.profile.items())}
-                                           if bfs.profile is not None else None),
+                                           if getattr(bfs, "profile", None) is not None else None),
         "roofline": {"bound": "hbm", "achieved": round(balg / wall / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": round(balg / wall / 1e9 / (8000.0 * world), 5), "traffic": None,
                      "note": "whole-step wall time (kernels + collectives), all ranks"},

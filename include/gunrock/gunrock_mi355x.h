@@ -216,6 +216,33 @@ int grx_pbfs_bottom_up(grx_pbfs *p, const unsigned *d_gathered, int words_per_ra
 int grx_pbfs_bitmap_to_queue(grx_pbfs *p, unsigned *len, unsigned *edges);
 /* device pointer to the local labels (depth per owned vertex, local-id order, -1 unreached) */
 int grx_pbfs_labels(grx_pbfs *p, int **d_labels);
+/* device pointer to the local predecessors (GLOBAL id of a valid BFS parent per owned vertex; -1 source, -2 unreached);
+ * top-down discoveries carry a parent only when mark_pred was set (grx_pbfs_set_options) */
+int grx_pbfs_preds(grx_pbfs *p, int **d_preds);
+
+/* ---- the whole level loop inside the library: one call per search, the halo exchange through RCCL over xGMI ----
+ * The reference's enactor is a host loop around operator launches (bfs_enactor.cuh:208-553); this is that loop for the
+ * vertex-partitioned problem, with the per-level exchange of SURVEY 8(e) issued from C++ on the engine's stream:
+ *   top-down level : advance -> bucket by owner -> ncclAllGather of the P x P count matrix -> grouped ncclSend/ncclRecv of
+ *                    the ids (and, with mark_pred, of their parents) -> filter (claim, label, next frontier)
+ *                    -> ncclAllGather of the packed frontier tails (termination + direction rule);
+ *   bottom-up level: ONE ncclAllGather of the per-rank frontier bitmaps whose trailing word carries each rank's frontier
+ *                    size -> local sweep; the search stays bottom-up to the end once Beamer's edge rule fires.
+ * grx_rccl_unique_id: rank 0 creates the 128-byte ncclUniqueId, the caller distributes it (any channel) and every rank calls
+ * grx_pbfs_comm_init_rccl after grx_pbfs_init_device.  RCCL is dlopen'ed on first use (librccl.so.1). */
+int grx_rccl_unique_id(char id[128]);
+int grx_pbfs_comm_init_rccl(grx_pbfs *p, const char id[128]);
+/* the same loop with the three exchanges performed by the caller, synchronously, on device pointers (tests run several
+ * ranks on one GPU over gloo this way); counts and offsets are in 32-bit words, segments in rank order */
+typedef int (*grx_all_gather_fn)(void *ctx, const void *d_send, void *d_recv, size_t words_per_rank);
+typedef int (*grx_all_to_all_v_fn)(void *ctx, const void *d_send, const size_t *send_counts, const size_t *send_offsets,
+                                   void *d_recv, const size_t *recv_counts, const size_t *recv_offsets);
+int grx_pbfs_set_transport(grx_pbfs *p, void *ctx, grx_all_gather_fn all_gather, grx_all_to_all_v_fn all_to_all_v);
+/* mark_pred: exchange (id, parent) pairs on top-down levels; alpha: direction rule factor (<= 0 keeps 10) */
+int grx_pbfs_set_options(grx_pbfs *p, int mark_pred, float alpha);
+/* Reset + the whole search from `src` (a GLOBAL vertex id, the same on every rank); levels = BSP levels executed;
+ * elapsed_ms = device time of this rank from the reset to the last level (HIP events on the engine's stream) */
+int grx_pbfs_search(grx_pbfs *p, int src, int direction_optimizing, int *levels, float *elapsed_ms);
 void grx_pbfs_destroy(grx_pbfs *p);
 
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */

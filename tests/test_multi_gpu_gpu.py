@@ -69,3 +69,52 @@ def test_partitioned_bfs_hip_engine(tmp_path, world, backend, dobfs):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), backend, 15, dobfs, out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+def _library_worker(rank, world, port, backend, scale, dobfs, mark_pred, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gunrockinst_amd import multi_gpu as mg
+    from oracle import gr_oracle as o
+
+    g = o.rmat_seeded(scale, 8 << scale)
+    ro_d, ci_d = mg.partition_rmat_device(scale, 8, 0x6772, rank, world)
+    comm = mg.Comm()
+    eng = mg.HipEngine(g.nodes, world, rank, ro_d, ci_d, 0)
+    # the level loop runs inside the library: RCCL issued from C++ (world 1 here: one GPU), or the same loop with the
+    # exchanges handed back to gloo so that several ranks can share the GPU
+    bfs = mg.LibraryBfs(eng, comm, transport="rccl" if backend == "nccl" else "callbacks", mark_pred=mark_pred,
+                        alpha=1e9 if dobfs == "always" else 14.0)
+    src, _ = o.highest_degree_node(g)
+    deg = np.diff(g.row_offsets)
+    ok = True
+    for s in (src, int(np.nonzero(deg > 0)[0][-1]), int(np.nonzero(deg == 0)[0][0]), int(np.nonzero(deg == 1)[0][0])):
+        levels, ms = bfs.search(s, direction_optimizing=bool(dobfs))
+        full = mg.assemble_labels(comm, eng.labels(), g.nodes)
+        ref, _, depth = o.bfs(g, s)
+        ok = ok and bool((full == ref).all()) and levels in (depth - 1, depth) and ms >= 0.0
+        if mark_pred:   # north_star: parents as well as depths hold on N ranks (valid parent: the paths are not unique)
+            preds = mg.assemble_labels(comm, bfs.preds(), g.nodes)
+            ok = ok and o.check_bfs_preds(g, s, full, preds) == 0
+    eng.close()
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend,dobfs,mark_pred", [(1, "nccl", True, False), (1, "nccl", False, True), (1, "nccl", "always", True),
+                                                           (2, "gloo", True, True), (2, "gloo", False, True), (3, "gloo", True, False),
+                                                           (3, "gloo", "always", True), (4, "gloo", True, True)])
+def test_library_level_loop(tmp_path, world, backend, dobfs, mark_pred):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_library_worker, args=(world, _free_port(), backend, 15, dobfs, mark_pred, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"

@@ -3,7 +3,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-idx = max(i for i, nm in enumerate(names) if 'ResetKernel' in nm)
+anchor = sys.argv[2] if len(sys.argv) > 2 else 'ResetKernel'
+idx = max(i for i, nm in enumerate(names) if anchor in nm)
 t0 = int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
     nm = r['Kernel_Name']

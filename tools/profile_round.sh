@@ -2,7 +2,7 @@
 # Round profile: kernel-trace stats and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the default bench command.
 # Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
@@ -16,3 +16,5 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -o w -- python3 $root/bench.py --steps 10 --warmup 1 --no-cpu-baseline --skip-topdown-leg > $out/pmc_write.log 2>&1
 python3 $root/tools/pmc_summary.py $(find /tmp/p_write -name "*counter_collection.csv" | head -1) WRITE_SIZE > $out/pmc_write_size.json
 echo "write done"
+python3 -c "import sys,json; sys.path.insert(0,'$root'); import bench; json.dump({'source_sha': bench.source_fingerprint(), 'command': 'python3 bench.py [--no-cpu-baseline] (stats) / --steps 10 --warmup 1 --no-cpu-baseline --skip-topdown-leg (pmc)'}, open('$out/profile_meta.json','w'))"
+echo "meta done"
