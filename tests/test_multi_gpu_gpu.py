@@ -118,3 +118,10 @@ def test_library_level_loop(tmp_path, world, backend, dobfs, mark_pred):
     out = str(tmp_path / "result.txt")
     mp.spawn(_library_worker, args=(world, _free_port(), backend, 15, dobfs, mark_pred, out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+def test_library_level_loop_two_ranks_scale22(tmp_path):
+    # config 5's protocol with real peers at the largest scale the oracle checks in a second: 2 ranks share the GPU over gloo
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_library_worker, args=(2, _free_port(), "gloo", 22, True, True, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
