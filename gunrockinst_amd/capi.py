@@ -126,6 +126,16 @@ _SIGNATURES = {
                                  C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "grx_sssp_extract": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), i32p]),
     "grx_sssp_destroy": (None, [C.c_void_p]),
+    "grx_pr_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "grx_pr_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
+    "grx_pr_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grx_pr_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "grx_pr_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float]),
+    "grx_pr_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "grx_pr_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "grx_pr_extract": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), i32p, C.c_int]),
+    "grx_pr_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "grx_pr_destroy": (None, [C.c_void_p]),
     "grx_pbfs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "grx_pbfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grx_pbfs_reset": (C.c_int, [C.c_void_p, C.c_int]),
@@ -488,6 +498,117 @@ def gunrock_bc(nodes, row_offsets, col_indices, src=-1, queue_size=1.0, src_mode
     ebc = np.ctypeslib.as_array(C.cast(eptr, C.POINTER(C.c_float)), shape=(max(edges, 1),))[:edges].copy()
     C.CDLL(None).free(C.c_void_p(eptr))
     return bc, ebc
+
+
+def gunrock_pr(nodes, row_offsets, col_indices, src=-1, delta=0.85, error=0.01, max_iter=20, top_nodes=0, src_mode=SRC_MANUALLY,
+               col_offsets=None, row_indices=None, device=0):
+    """Call gunrock_pr_func as reference shared_lib_tests/test_pr.c does; returns (node_ids, page_rank) in descending rank order
+    (top_nodes entries, all of them when top_nodes <= 0).  col_offsets / row_indices: the graph's CSC, when the caller has it."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    gin = _graph_struct(nodes, ro, ci)
+    keep = []
+    if col_offsets is not None and row_indices is not None:
+        co = np.ascontiguousarray(col_offsets, dtype=np.int32)
+        ri = np.ascontiguousarray(row_indices, dtype=np.int32)
+        gin.col_offsets, gin.row_indices = co.ctypes.data, ri.ctypes.data
+        keep = [co, ri]
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.src_node, cfg.device, cfg.src_mode = src, device, src_mode
+    cfg.delta, cfg.error, cfg.max_iter, cfg.top_nodes = delta, error, max_iter, top_nodes
+    count = nodes if top_nodes <= 0 else min(nodes, top_nodes)
+    ids = np.empty(max(count, 1), dtype=np.int32)
+    ranks = np.empty(max(count, 1), dtype=np.float32)
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_FLOAT)
+    lib().gunrock_pr_func(C.byref(gout), ids.ctypes.data_as(C.c_void_p), ranks.ctypes.data_as(C.c_void_p), C.byref(gin), cfg, dt)
+    del keep
+    return ids[:count], ranks[:count]
+
+
+def gunrock_topk(nodes, row_offsets, col_indices, col_offsets, row_indices, top_nodes, device=0):
+    """Call gunrock_topk_func as reference shared_lib_tests/test_topk.c does; returns (node_ids, in_degrees, out_degrees)."""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+    co = np.ascontiguousarray(col_offsets, dtype=np.int32)
+    ri = np.ascontiguousarray(row_indices, dtype=np.int32)
+    gin = _graph_struct(nodes, ro, ci)
+    gin.col_offsets, gin.row_indices = co.ctypes.data, ri.ctypes.data
+    gout = GunrockGraph()
+    cfg = GunrockConfig()
+    cfg.device, cfg.top_nodes = device, top_nodes
+    k = max(min(nodes, top_nodes), 1)
+    ids, ind, outd = (np.empty(k, dtype=np.int32) for _ in range(3))
+    dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_INT)
+    lib().gunrock_topk_func(C.byref(gout), ids.ctypes.data_as(C.c_void_p), ind.ctypes.data_as(C.c_void_p), outd.ctypes.data_as(C.c_void_p),
+                            C.byref(gin), cfg, dt)
+    k = min(nodes, top_nodes)
+    return ids[:k], ind[:k], outd[:k]
+
+
+class PrProblem:
+    """PRProblem + PREnactor behind the handle ABI (grx_pr_*)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().grx_pr_create(C.byref(self._h), device), "grx_pr_create")
+        self.nodes = self.edges = 0
+
+    def init(self, nodes, row_offsets, col_indices):
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.int32)
+        self.nodes, self.edges = int(nodes), int(ci.shape[0])
+        _check(lib().grx_pr_init(self._h, self.nodes, self.edges, _p(ro), _p(ci)), "PRProblem::Init")
+        return self
+
+    def init_device(self, nodes, edges, d_row_offsets, d_col_indices):
+        self.nodes, self.edges = int(nodes), int(edges)
+        _check(lib().grx_pr_init_device(self._h, self.nodes, self.edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices)),
+               "PRProblem::Init (device)")
+        return self
+
+    def set_inverse_graph(self, d_inv_row_offsets=None, d_inv_col_indices=None, build=False):
+        """No arguments: the graph is symmetric (its CSR is its own inverse); build=True: transpose on the device."""
+        _check(lib().grx_pr_set_inverse_graph(self._h, C.c_void_p(d_inv_row_offsets), C.c_void_p(d_inv_col_indices), int(bool(build))),
+               "PRProblem::SetInverseGraph")
+        return self
+
+    def reset(self, src=-1, delta=0.85, threshold=0.01):
+        _check(lib().grx_pr_reset(self._h, int(src), float(delta), float(threshold)), "PRProblem::Reset")
+        return self
+
+    def enact(self, max_iter=20, max_grid_size=0):
+        ms = C.c_float()
+        _check(lib().grx_pr_enact(self._h, int(max_iter), int(max_grid_size), C.byref(ms)), "PREnactor::Enact")
+        return float(ms.value)
+
+    def stats(self):
+        it, pr, sv = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(lib().grx_pr_stats(self._h, C.byref(it), C.byref(pr), C.byref(sv)), "grx_pr_stats")
+        return {"iterations": int(it.value), "peeling_rounds": int(pr.value), "surviving_nodes": int(sv.value)}
+
+    def extract(self, count=-1):
+        k = self.nodes if count < 0 else min(count, self.nodes)
+        ranks = np.empty(max(k, 1), dtype=np.float32)
+        ids = np.empty(max(k, 1), dtype=np.int32)
+        _check(lib().grx_pr_extract(self._h, ranks.ctypes.data_as(C.POINTER(C.c_float)), _p(ids), k), "PRProblem::Extract")
+        return ids[:k], ranks[:k]
+
+    def device_results(self):
+        r, i = C.c_void_p(), C.c_void_p()
+        _check(lib().grx_pr_device_results(self._h, C.byref(r), C.byref(i)), "grx_pr_device_results")
+        return r.value, i.value
+
+    def close(self):
+        if self._h:
+            lib().grx_pr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BcProblem:

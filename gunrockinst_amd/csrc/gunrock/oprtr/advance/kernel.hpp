@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <climits>
+#include <limits>
 #include <type_traits>
 
 #include <gunrock/oprtr/advance/binned.hpp>
@@ -38,6 +39,10 @@ namespace advance {
 // Names kept from advance/kernel_policy.cuh:43-75.  Only the forward modes are in scope.
 enum MODE { TWC_FORWARD, TWC_BACKWARD, LB_BACKWARD, LB };
 enum TYPE { V2V, V2E, E2V, E2E };
+// Neighbour-list reduction of an advance (names from advance/kernel_policy.cuh:58-79): per input-frontier vertex, the
+// REDUCE_OP of a value taken per out-edge -- at the edge's destination (VERTEX) or at the edge itself (EDGE).
+enum REDUCE_OP { NONE, PLUS, MINUS, MULTIPLIES, MODULUS, BIT_OR, BIT_AND, BIT_XOR, MAXIMUM, MINIMUM };
+enum REDUCE_TYPE { EMPTY, VERTEX, EDGE };
 
 // Tuning surface reduced to what matters on CDNA4 (the reference's 14-integer policies are CUDA
 // occupancy detail).
@@ -63,6 +68,8 @@ struct AdvanceArgs {
     unsigned long long *d_tail_clear;  // ring slot to zero for the step after next
     int *d_overflow;
     BinPool<VertexId> bins;            // BINNED advance only (binned.hpp): where phase 1 hands its survivors
+    const void *d_value_to_reduce = nullptr;  // reducing advance only (LaunchReduce): values indexed by vertex / by edge ...
+    void *d_reduced_value = nullptr;          // ... and the per-frontier-entry results
 };
 
 // Frontier-array load.  FRESH = the arrays were written earlier in the SAME launch (multi-level tail kernel): read
@@ -76,6 +83,76 @@ __device__ __forceinline__ T LoadQueue(const T *p)
 }
 
 struct NoWriterStorage {};
+
+// ---- reduction policy of an advance (reference: R_TYPE / R_OP of advance::LaunchKernel + moderngpu SegReduceCsr over the
+//      scanned edge slots, advance/kernel.cuh:733-761, edge_map_partitioned/kernel.cuh:417-480) ----
+struct NoReduce {
+    static constexpr bool ENABLED = false;
+};
+
+template <REDUCE_OP OP, typename T>
+struct ReduceOps {
+    static __device__ __forceinline__ T Identity()
+    {
+        if (OP == MULTIPLIES) return static_cast<T>(1);
+        if (OP == MAXIMUM) return std::numeric_limits<T>::lowest();
+        if (OP == MINIMUM) return std::numeric_limits<T>::max();
+        if (OP == BIT_AND) return static_cast<T>(~0ull);
+        return static_cast<T>(0);  // PLUS, BIT_OR, BIT_XOR (and the operators without a reduction meaning)
+    }
+    static __device__ __forceinline__ T Combine(T a, T b)
+    {
+        if constexpr (OP == MULTIPLIES) return a * b;
+        else if constexpr (OP == MAXIMUM) return a > b ? a : b;
+        else if constexpr (OP == MINIMUM) return a < b ? a : b;
+        else if constexpr (OP == BIT_OR || OP == BIT_AND || OP == BIT_XOR) {
+            static_assert(!(OP == BIT_OR || OP == BIT_AND || OP == BIT_XOR) || std::is_integral<T>::value, "bitwise reductions need an integer type");
+            if constexpr (OP == BIT_OR) return a | b;
+            else if constexpr (OP == BIT_AND) return a & b;
+            else return a ^ b;
+        } else return a + b;
+    }
+    // combine `v` into *p (another workgroup or wave may hold the other part of the same neighbour list)
+    static __device__ __forceinline__ void AtomicCombine(T *p, T v)
+    {
+        if constexpr (OP == PLUS || OP == NONE || OP == MINUS || OP == MODULUS) {
+            atomicAdd(p, v);
+        } else if constexpr (std::is_integral<T>::value && sizeof(T) == 4 && (OP == MAXIMUM || OP == MINIMUM || OP == BIT_OR || OP == BIT_AND || OP == BIT_XOR)) {
+            if constexpr (OP == MAXIMUM) atomicMax(p, v);
+            else if constexpr (OP == MINIMUM) atomicMin(p, v);
+            else if constexpr (OP == BIT_OR) atomicOr(p, v);
+            else if constexpr (OP == BIT_AND) atomicAnd(p, v);
+            else atomicXor(p, v);
+        } else {  // compare-and-swap loop on the value's bits
+            static_assert(sizeof(T) == 4, "32-bit values");
+            unsigned *q = reinterpret_cast<unsigned *>(p);
+            unsigned seen = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                T cur;
+                __builtin_memcpy(&cur, &seen, 4);
+                const T want = Combine(cur, v);
+                unsigned bits;
+                __builtin_memcpy(&bits, &want, 4);
+                if (bits == seen) break;
+                const unsigned old = atomicCAS(q, seen, bits);
+                if (old == seen) break;
+                seen = old;
+            }
+        }
+    }
+};
+
+// BY_VERTEX: the result of a frontier entry lands at d_reduced_value[its vertex id] instead of [its position in the frontier]
+// (the reference indexes by position, advance/kernel.cuh:738; by vertex saves the scatter pass a vertex-indexed consumer needs)
+template <REDUCE_TYPE _R_TYPE, REDUCE_OP _R_OP, typename _Value, bool _BY_VERTEX = false>
+struct Reduce {
+    static constexpr bool ENABLED = true;
+    static constexpr bool BY_VERTEX = _BY_VERTEX;
+    static constexpr REDUCE_TYPE R_TYPE = _R_TYPE;
+    static constexpr REDUCE_OP R_OP = _R_OP;
+    typedef _Value Value;
+    typedef ReduceOps<_R_OP, _Value> Ops;
+};
 
 template <typename KernelPolicy, typename VertexId, typename SizeT, bool WITH_WRITER = true>
 struct AdvanceShared {
@@ -120,8 +197,11 @@ __device__ __forceinline__ void InitOwnerMarks(Shared &sh, unsigned &tile_tag)
 // the mark (tag | j) at the slot where j's row begins; a wave owns ITEMS x 64 CONSECUTIVE slots, finds the owner of its
 // first slot with one (wave-uniform) search and resolves the rest with an inclusive max-scan over the marks on the DPP
 // path.  Tags make stale marks of earlier tiles lose every max, so the marks are never cleared.
+// Reducer = Reduce<R_TYPE, R_OP, Value> (with COUNT_ONLY): besides CondEdge / ApplyEdge, the edge slots of every frontier entry
+// are reduced into a.d_reduced_value[entry] (pre-set to the operator's identity): a wave-segmented scan over each run of
+// consecutive slots with the same owner, then ONE plain store when the run is the entry's whole neighbour list, else one atomic.
 template <typename KernelPolicy, typename ProblemData, typename Functor, bool OUT_WITH_DEGREES, bool FRESH, bool COUNT_ONLY = false,
-          bool BINNED = false, typename Shared>
+          bool BINNED = false, typename Reducer = NoReduce, typename Shared>
 __device__ __forceinline__ void ExpandTiles(
     const AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a, typename ProblemData::DataSlice &slice,
     const long long tile_begin, const long long tile_end, Shared &sh, unsigned &accepted, unsigned &tile_tag)
@@ -242,6 +322,7 @@ __device__ __forceinline__ void ExpandTiles(
         VertexId src[ITEMS];
         VertexId dst[ITEMS];
         bool live[ITEMS];
+        int own[Reducer::ENABLED ? ITEMS : 1];  // staged entry that owns the slot (reducing advance only)
         {
             int lo = 0, hi = owners;  // sh.scan[lo] <= wave_base < sh.scan[hi] (hi == owners: past the slice)
             if (wave_base > 0) {
@@ -262,6 +343,7 @@ __device__ __forceinline__ void ExpandTiles(
                 const int owner = static_cast<int>(m & static_cast<unsigned>(THREADS - 1));
                 edge[k] = sh.row[owner] + (slot - sh.scan[owner]);
                 src[k] = sh.vertex[owner];
+                if constexpr (Reducer::ENABLED) own[k] = owner;
             }
         }
         // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
@@ -303,6 +385,42 @@ __device__ __forceinline__ void ExpandTiles(
                                            slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
                         ++mine;
                     }
+                }
+            }
+        }
+        if constexpr (Reducer::ENABLED) {
+            typedef typename Reducer::Value RValue;
+            typedef typename Reducer::Ops Ops;
+            const RValue *values = static_cast<const RValue *>(a.d_value_to_reduce);
+            RValue *reduced = static_cast<RValue *>(a.d_reduced_value);
+            RValue val[ITEMS];
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {  // all value loads in flight together (rejected slots read entry 0, then take the identity)
+                const RValue got = values[live[k] ? (Reducer::R_TYPE == VERTEX ? static_cast<SizeT>(dst[k]) : edge[k]) : static_cast<SizeT>(0)];
+                val[k] = live[k] ? got : Ops::Identity();
+            }
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int row_first = wave_base + k * util::kWaveSize;
+                const int slot = row_first + static_cast<int>(lane);
+                const int key = slot < slots ? own[k] : -1;  // owners are non-decreasing along the slots: equal keys are one run
+                RValue v = val[k];
+#pragma unroll
+                for (int o = 1; o < util::kWaveSize; o <<= 1) {
+                    const int other_key = __shfl_up(key, o, util::kWaveSize);
+                    const RValue other = __shfl_up(v, o, util::kWaveSize);
+                    if (static_cast<int>(lane) >= o && other_key == key) v = Ops::Combine(other, v);
+                }
+                const int next_key = __shfl_down(key, 1, util::kWaveSize);
+                if (key >= 0 && (lane == util::kWaveSize - 1 || next_key != key)) {  // last slot of the run
+                    const int row_begin = sh.scan[key];
+                    const int row_end = key + 1 < THREADS ? sh.scan[key + 1] : INT_MAX;  // (INT_MAX past the frontier too: the last entry's
+                                                                                        //  list ends with the slots)
+                    const bool ends_here = row_end - 1 == slot || (row_end == INT_MAX && key + 1 < THREADS && slot == slots - 1 &&
+                                                                  slot_at + slots >= total);
+                    const long long at = Reducer::BY_VERTEX ? static_cast<long long>(sh.vertex[key]) : static_cast<long long>(cursor) + key;
+                    if (row_begin >= row_first && ends_here) reduced[at] = v;   // the whole neighbour list sat in this run
+                    else Ops::AtomicCombine(reduced + at, v);
                 }
             }
         }
@@ -515,6 +633,73 @@ hipError_t LaunchKernel(const AdvanceArgs<typename ProblemData::VertexId, typena
     hipLaunchKernelGGL((LoadBalancedKernel<KernelPolicy, ProblemData, Functor, OUT_WITH_DEGREES, COUNT_ONLY>), dim3(static_cast<unsigned>(grid)),
                        dim3(KernelPolicy::THREADS), 0, stream, args, slice);
     return util::GRError("advance::LoadBalancedKernel launch failed", __FILE__, __LINE__);
+}
+
+// ---- reducing advance: CondEdge / ApplyEdge as usual, plus the per-frontier-entry reduction of a value per edge ----
+template <typename KernelPolicy, typename ProblemData, typename Functor, typename Reducer>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void ReduceKernel(
+    AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice)
+{
+    typedef typename ProblemData::VertexId VertexId;
+    typedef typename ProblemData::SizeT SizeT;
+    typedef AdvanceShared<KernelPolicy, VertexId, SizeT, false> Shared;
+    __shared__ Shared sh;
+    unsigned tile_tag;
+    InitOwnerMarks<KernelPolicy>(sh, tile_tag);
+    const long long tiles = (static_cast<long long>(a.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    const long long per_block = (tiles + gridDim.x - 1) / gridDim.x;
+    const long long tile_begin = static_cast<long long>(blockIdx.x) * per_block;
+    const long long tile_end = (tile_begin + per_block < tiles) ? tile_begin + per_block : tiles;
+    if (tile_begin >= tile_end) return;
+    __syncthreads();
+    unsigned accepted = 0;
+    ExpandTiles<KernelPolicy, ProblemData, Functor, false, false, true, false, Reducer>(a, slice, tile_begin, tile_end, sh, accepted, tile_tag);
+}
+
+template <typename T>
+__global__ void FillKernel(T *d_out, T value, long long n)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) d_out[i] = value;
+}
+
+template <REDUCE_OP OP, typename T>
+inline T HostIdentity()
+{
+    if (OP == MULTIPLIES) return static_cast<T>(1);
+    if (OP == MAXIMUM) return std::numeric_limits<T>::lowest();
+    if (OP == MINIMUM) return std::numeric_limits<T>::max();
+    if (OP == BIT_AND) return static_cast<T>(~0ull);
+    return static_cast<T>(0);
+}
+
+// advance::LaunchKernel with R_TYPE / R_OP (advance/kernel.cuh:101-129): d_reduced_value[i] = R_OP over the out-edges e = (v, u)
+// of input-frontier entry i = (v) that pass CondEdge of d_value_to_reduce[u] (VERTEX) or d_value_to_reduce[e] (EDGE); entries
+// whose every edge fails get the operator's identity.  ApplyEdge runs for the passing edges as in a plain advance; nothing is
+// enqueued.  One launch (plus the identity fill): no device-wide segmented-reduce pass over a materialised edge-value array.
+// BY_VERTEX: results indexed by vertex id; `out_len` = entries of d_reduced_value to pre-set (0 = the frontier length).
+template <typename KernelPolicy, typename ProblemData, typename Functor, REDUCE_TYPE R_TYPE, REDUCE_OP R_OP, typename Value, bool BY_VERTEX = false>
+hipError_t LaunchReduce(AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> args,
+                        const typename ProblemData::DataSlice &slice, const Value *d_value_to_reduce, Value *d_reduced_value,
+                        int max_grid_size, hipStream_t stream, long long out_len = 0)
+{
+    static_assert(R_TYPE != EMPTY && R_OP != NONE, "a reducing advance needs a reduction");
+    if (out_len <= 0) out_len = args.in_len;
+    if (out_len <= 0) return hipSuccess;
+    hipLaunchKernelGGL((FillKernel<Value>), dim3(static_cast<unsigned>((out_len + 1023) / 1024 < 2048 ? (out_len + 1023) / 1024 : 2048)),
+                       dim3(256), 0, stream, d_reduced_value, HostIdentity<R_OP, Value>(), out_len);
+    hipError_t rc = util::GRError("advance::FillKernel launch failed", __FILE__, __LINE__);
+    if (rc || args.in_edges <= 0 || args.in_len <= 0) return rc;
+    args.d_value_to_reduce = d_value_to_reduce;
+    args.d_reduced_value = d_reduced_value;
+    typedef Reduce<R_TYPE, R_OP, Value, BY_VERTEX> Reducer;
+    const long long tiles = (static_cast<long long>(args.in_edges) + KernelPolicy::TILE - 1) / KernelPolicy::TILE;
+    if (max_grid_size <= 0) max_grid_size = util::ResidentGrid(ReduceKernel<KernelPolicy, ProblemData, Functor, Reducer>, KernelPolicy::THREADS);
+    long long grid = tiles < max_grid_size ? tiles : max_grid_size;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((ReduceKernel<KernelPolicy, ProblemData, Functor, Reducer>), dim3(static_cast<unsigned>(grid)),
+                       dim3(KernelPolicy::THREADS), 0, stream, args, slice);
+    return util::GRError("advance::ReduceKernel launch failed", __FILE__, __LINE__);
 }
 
 // ---- persistent multi-workgroup levels: the same idea for MID-SIZE frontiers (8 K .. ~1 M edge slots) ----

@@ -262,6 +262,34 @@ int grx_bc_run(grx_bc *p, int src, int max_grid_size, double queue_sizing, float
 int grx_bc_extract(grx_bc *p, float *h_sigmas, float *h_bc_values, float *h_ebc_values);
 void grx_bc_destroy(grx_bc *p);
 
+/* ------------------------------------------------------------------------------------------------
+ * PageRank: PRProblem + PREnactor (reference gunrock/app/pr/pr_problem.cuh:36-467, pr_enactor.cuh:36-622), the <int, float, int>
+ * instantiation of its C entry point (pr_app.cu:213-296).  Ranks are pulled over the in-neighbour lists by the reducing
+ * advance (the reference's R_TYPE / R_OP advance + SegReduceCsr, advance/kernel.cuh:733-761), so the problem needs the
+ * inverse graph.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct grx_pr grx_pr;
+int grx_pr_create(grx_pr **out, int device);
+/* PRProblem::Init (pr_problem.cuh:186-307): host CSR in / device CSR borrowed */
+int grx_pr_init(grx_pr *p, int nodes, int edges, const int *row_offsets, const int *col_indices);
+int grx_pr_init_device(grx_pr *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices);
+/* in-neighbour lists: device CSC arrays (borrowed); or NULL, NULL with build_if_null = 0 for a symmetric graph (its CSR is its
+ * own inverse) or build_if_null != 0 to have the transpose built on the device.  Call after init. */
+int grx_pr_set_inverse_graph(grx_pr *p, const int *d_inv_row_offsets, const int *d_inv_col_indices, int build_if_null);
+/* PRProblem::Reset(src, delta, threshold, frontier_type) (pr_problem.cuh:316-457); src = -1: every vertex teleports */
+int grx_pr_reset(grx_pr *p, int src, float delta, float threshold);
+/* PREnactor::Enact(context, problem, max_iteration, traversal_mode, max_grid_size) (pr_enactor.cuh:536-618), HIP-event timed */
+int grx_pr_enact(grx_pr *p, int max_iter, int max_grid_size, float *elapsed_ms);
+/* iterations run, peeling rounds (vertices without out-edges are removed round by round first, pr_enactor.cuh:220-300) and the
+ * number of vertices left after peeling */
+int grx_pr_stats(grx_pr *p, long long *iterations, long long *peeling_rounds, long long *surviving_nodes);
+/* PRProblem::Extract (pr_problem.cuh:139-175): the first `count` ranks in descending order with their vertex ids
+ * (count < 0: all); either pointer may be NULL */
+int grx_pr_extract(grx_pr *p, float *h_rank_sorted, int *h_node_ids, int count);
+/* device arrays: ranks indexed by vertex, vertex ids by descending rank */
+int grx_pr_device_results(grx_pr *p, float **d_rank_by_vertex, int **d_node_ids_by_rank);
+void grx_pr_destroy(grx_pr *p);
+
 const char *grx_version(void);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@
 #endif
 
 #include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -651,4 +652,101 @@ int gro_bc(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t src, dou
     for (int32_t v = 0; v < nodes; ++v) bc_out[v] *= 0.5;
     free(order); free(label); free(sigma); free(delta);
     return 0;
+}
+
+/* ---- PageRank: CPU restatement of the reference's GPU schedule (there is no CPU PageRank in its C-ABI path; its driver
+ *      compares against Boost's page_rank, tests/pr/test_pr.cu, which is not installable here).
+ *      gunrock/app/pr/pr_enactor.cuh:220-300  peeling of vertices without out-edges, round by round;
+ *      pr_functor.cuh:52-71   an edge s->d with both ends alive moves rank[s] / degree[s] to d;
+ *      pr_functor.cuh:84-93   rank = delta * sum + (1 - delta) * [vertex is the source, or source == -1]; a vertex is active
+ *                             while |new - old| > threshold;
+ *      pr_enactor.cuh:478-498 ranks of ALL vertices are replaced by the sums' array (peeled vertices end at 0); stop when no
+ *                             vertex is active or after max_iter iterations (at least one iteration runs);
+ *      pr_problem.cuh:423     initial rank 1 - delta.
+ *      Accumulation here is double and in vertex order; the GPU sums floats in another order: compare with a tolerance.
+ *      PARITY UNPINNED: the reference's ctest answer for this path ("Node ID 2: Page Rank 0.402378", CMakeLists.txt:231-233)
+ *      is not what the code in the tree computes for shared_lib_tests/test_pr.c (node 2 converges to 0.398 and never passes
+ *      through 0.402378); tests/test_oracle.py records the search. ---- */
+int gro_pagerank(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t src, double delta, double threshold, int32_t max_iter,
+                 double *rank_out, int32_t *degrees_out, int32_t *iterations_out)
+{
+    int32_t *deg = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nodes > 0 ? nodes : 1));
+    int32_t *pong = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nodes > 0 ? nodes : 1));
+    double *cur = (double *)malloc(sizeof(double) * (size_t)(nodes > 0 ? nodes : 1));
+    double *nxt = (double *)malloc(sizeof(double) * (size_t)(nodes > 0 ? nodes : 1));
+    if (!deg || !pong || !cur || !nxt) return -1;
+    for (int32_t v = 0; v < nodes; ++v) deg[v] = ro[v + 1] - ro[v];
+    for (;;) {                                       /* peeling rounds */
+        int64_t removed = 0;
+        for (int32_t v = 0; v < nodes; ++v) pong[v] = deg[v] == 0 ? -1 : deg[v];
+        for (int32_t s = 0; s < nodes; ++s) {
+            if (deg[s] <= 0) continue;               /* only queued vertices expand; a vertex at 0 is retired this round */
+            for (int32_t e = ro[s]; e < ro[s + 1]; ++e)
+                if (deg[ci[e]] == 0) pong[s] -= 1;
+        }
+        for (int32_t v = 0; v < nodes; ++v) if (deg[v] == 0) removed++;
+        memcpy(deg, pong, sizeof(int32_t) * (size_t)nodes);
+        if (!removed) break;
+    }
+    for (int32_t v = 0; v < nodes; ++v) { cur[v] = 1.0 - delta; nxt[v] = 0.0; }
+    int32_t it = 0;
+    int64_t alive = 0;
+    for (int32_t v = 0; v < nodes; ++v) alive += deg[v] > 0;
+    while (alive > 0) {
+        for (int32_t s = 0; s < nodes; ++s) {
+            if (deg[s] <= 0) continue;
+            const double c = (double)(float)((float)cur[s] / (float)deg[s]);   /* the GPU divides in float */
+            for (int32_t e = ro[s]; e < ro[s + 1]; ++e)
+                if (deg[ci[e]] > 0) nxt[ci[e]] += c;
+        }
+        int64_t active = 0;
+        for (int32_t v = 0; v < nodes; ++v) {
+            if (deg[v] <= 0) continue;
+            nxt[v] = delta * nxt[v] + (1.0 - delta) * ((src == v || src == -1) ? 1.0 : 0.0);
+            if (fabs(nxt[v] - cur[v]) > threshold) active++;
+        }
+        for (int32_t v = 0; v < nodes; ++v) { cur[v] = nxt[v]; nxt[v] = 0.0; }
+        ++it;
+        if (active == 0 || it >= max_iter) break;
+    }
+    for (int32_t v = 0; v < nodes; ++v) rank_out[v] = cur[v];
+    if (degrees_out) memcpy(degrees_out, deg, sizeof(int32_t) * (size_t)nodes);
+    if (iterations_out) *iterations_out = it;
+    free(deg); free(pong); free(cur); free(nxt);
+    return 0;
+}
+
+/* ---- TopK degree centrality (gunrock/app/topk/topk_enactor.cuh:236-272): vertices by descending in + out degree; the
+ *      reference's stable pair sort leaves ties in ascending vertex order. ---- */
+void gro_topk(const int32_t *ro, const int32_t *co, int32_t nodes, int32_t k, int32_t *ids, int32_t *in_deg, int32_t *out_deg)
+{
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nodes > 0 ? nodes : 1));
+    for (int32_t v = 0; v < nodes; ++v) order[v] = v;
+    /* insertion into a sorted prefix of length k: O(n k), fine for a checker */
+    for (int32_t i = 0; i < nodes; ++i) {
+        const int32_t v = order[i];
+        const int64_t tv = (int64_t)(ro[v + 1] - ro[v]) + (co ? co[v + 1] - co[v] : 0);
+        int32_t j = i < k ? i : k;
+        if (i >= k) {
+            const int32_t w = order[k - 1];
+            const int64_t tw = (int64_t)(ro[w + 1] - ro[w]) + (co ? co[w + 1] - co[w] : 0);
+            if (tv <= tw) continue;
+            j = k - 1;
+        }
+        while (j > 0) {
+            const int32_t w = order[j - 1];
+            const int64_t tw = (int64_t)(ro[w + 1] - ro[w]) + (co ? co[w + 1] - co[w] : 0);
+            if (tw >= tv) break;
+            order[j] = w;
+            --j;
+        }
+        order[j] = v;
+    }
+    for (int32_t i = 0; i < k && i < nodes; ++i) {
+        const int32_t v = order[i];
+        ids[i] = v;
+        out_deg[i] = ro[v + 1] - ro[v];
+        in_deg[i] = co ? co[v + 1] - co[v] : 0;
+    }
+    free(order);
 }

@@ -126,4 +126,12 @@ int gro_bc(const int32_t *row_offsets, const int32_t *col_indices, int32_t nodes
 #ifdef __cplusplus
 }
 #endif
+/* PageRank with the reference's GPU schedule (pr_enactor.cuh / pr_functor.cuh), doubles; degrees_out = out-degrees after
+ * peeling (-1 peeled), iterations_out = iterations run.  PARITY UNPINNED (see gr_oracle.c). */
+int gro_pagerank(const int32_t *row_offsets, const int32_t *col_indices, int32_t nodes, int32_t src, double delta, double threshold,
+                 int32_t max_iter, double *rank_out, int32_t *degrees_out, int32_t *iterations_out);
+/* TopK degree centrality (topk_enactor.cuh:236-272); col_offsets may be NULL (in-degrees 0) */
+void gro_topk(const int32_t *row_offsets, const int32_t *col_offsets, int32_t nodes, int32_t k, int32_t *ids, int32_t *in_degrees,
+              int32_t *out_degrees);
+
 #endif

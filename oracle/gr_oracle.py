@@ -57,6 +57,10 @@ def lib():
         L.gro_check_bfs_preds.restype = C.c_int64
         L.gro_check_sssp_preds.argtypes = [i32p, i32p, u32p, C.c_int32, C.c_int32, u32p, i32p]
         L.gro_check_sssp_preds.restype = C.c_int64
+        L.gro_pagerank.argtypes = [i32p, i32p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double), i32p, i32p]
+        L.gro_pagerank.restype = C.c_int
+        L.gro_topk.argtypes = [i32p, i32p, C.c_int32, C.c_int32, i32p, i32p, i32p]
+        L.gro_topk.restype = None
         L.gro_csr_free.argtypes = [C.POINTER(_Csr)]
         L.gro_csr_free.restype = None
         L.gro_srand.argtypes = [C.c_uint]
@@ -203,6 +207,26 @@ def bc(g, src=-1):
     rc = lib().gro_bc(_p(g.row_offsets), _p(g.col_indices), g.nodes, int(src), out.ctypes.data_as(f64p), sig.ctypes.data_as(f64p))
     assert rc == 0
     return out[:g.nodes], sig[:g.nodes]
+
+
+def pagerank(g, src=-1, delta=0.85, threshold=0.01, max_iter=20):
+    """The reference's PageRank schedule in doubles; returns (rank float64[n], degrees after peeling int32[n], iterations).
+    PARITY UNPINNED: see gr_oracle.c."""
+    rank = np.empty(max(g.nodes, 1), dtype=np.float64)
+    deg = np.empty(max(g.nodes, 1), dtype=np.int32)
+    it = C.c_int32()
+    rc = lib().gro_pagerank(_p(g.row_offsets), _p(g.col_indices), g.nodes, int(src), float(delta), float(threshold), int(max_iter),
+                            rank.ctypes.data_as(C.POINTER(C.c_double)), _p(deg), C.byref(it))
+    assert rc == 0
+    return rank[:g.nodes], deg[:g.nodes], int(it.value)
+
+
+def topk(g, k, col_offsets=None):
+    k = min(int(k), g.nodes)
+    ids, ind, outd = (np.empty(max(k, 1), dtype=np.int32) for _ in range(3))
+    co = None if col_offsets is None else np.ascontiguousarray(col_offsets, dtype=np.int32)
+    lib().gro_topk(_p(g.row_offsets), None if co is None else _p(co), g.nodes, k, _p(ids), _p(ind), _p(outd))
+    return ids[:k], ind[:k], outd[:k]
 
 
 def bfs_stats(g, labels):

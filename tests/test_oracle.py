@@ -118,3 +118,34 @@ def test_parallel_bfs_baseline_gives_the_serial_labels():
             labels, used = o.bfs_parallel(g, src, threads)
             assert np.array_equal(labels, ref)
             assert used >= 1
+
+
+def test_pagerank_and_topk_restatements(golden):
+    f = golden["fixture7"]
+    g = o.Csr(7, f["row_offsets"], f["col_indices"])
+    # TopK: pinned by the reference's ctest answer "Node ID.*2.*: in_degrees.*3.*: out_degrees.*3" (CMakeLists.txt:235-237),
+    # inputs of shared_lib_tests/test_topk.c:27-31
+    ids, ind, outd = o.topk(g, 3, [0, 1, 2, 5, 7, 9, 12, 15])
+    assert (int(ids[0]), int(ind[0]), int(outd[0])) == (2, 3, 3)
+    # PageRank on shared_lib_tests/test_pr.c's inputs: vertices 6, 5, 3 are peeled off in three rounds, the rest converges
+    rank, deg, iters = o.pagerank(g, 0, 0.85, 0.01, 20)
+    assert deg.tolist() == [2, 3, 1, -1, 1, -1, -1] and iters == 10
+    assert int(np.argmax(rank)) == 2 and abs(rank[2] - 0.357589) < 1e-5
+    # fixed point of the 4-vertex system that is left (solved by hand in DESIGN.md): r2 = 0.3981
+    far, _, _ = o.pagerank(g, 0, 0.85, 0.0, 200)
+    assert abs(far[2] - 0.39810) < 1e-4
+
+
+def test_pagerank_ctest_answer_is_stale(golden):
+    """The reference's ctest expects "Node ID.*2.*: Page Rank.*0.402378" from shared_lib_tests/test_pr.c (CMakeLists.txt:231-233).
+    The code in the tree cannot print it: from every starting point tried, vertex 2's rank moves monotonically towards the fixed
+    point 0.3981 and never passes through 0.402378 -- the regex predates the code (like gunrock/app/sssp/sssp_app.cu, which no
+    longer compiles).  So PageRank parity is UNPINNED; this test keeps the evidence."""
+    f = golden["fixture7"]
+    g = o.Csr(7, f["row_offsets"], f["col_indices"])
+    seen = []
+    for src in (0, -1):
+        for iters in range(1, 41):
+            rank, _, _ = o.pagerank(g, src, 0.85, 0.0, iters)
+            seen.append(float(rank[2]))
+    assert all(abs(x - 0.402378) > 1e-4 for x in seen)
