@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("test_cc", r"Node_ID.*1.*: Component_ID.*0"),
     ("test_sssp", r"Node ID.*1.*: Label.*39.*: Predecessor.*0"),
     ("test_bc", r"Node_ID.*0.*: BC.*0.500000"),
+    ("test_topk", r"Node ID.*2.*: in_degrees.*3.*: out_degrees.*3"),     # reference ctest TestTopK (CMakeLists.txt:235-237)
+    ("test_pr", r"Node ID \[2\] : Page Rank \[0\.3575"),                   # the oracle's value; the reference's regex is stale
 ])
 def test_c_program_known_answer(name, regex):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), name, "-s"])
