@@ -4,12 +4,16 @@
 // the primitives in scope: load the graph UNDIRECTED (:760), connected components on the GPU checked against a host
 // union-find (component count, as the reference does with Boost :437-445, plus the labels), histogram, BFS from the root
 // of the largest component in idempotent mode (:453-499) checked label by label against a host FIFO BFS (:566), then
-// "TEST PASSED" / "TEST FAILED" (:682-687).  The reference's third stage (BC) is out of scope.
+// betweenness centrality from every vertex (:592-672: Reset + Enact per source, values halved) checked against a host Brandes
+// pass with the reference's float tolerance, then "TEST PASSED" / "TEST FAILED" (:682-687).
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <deque>
 #include <vector>
 
+#include <gunrock/app/bc/bc_enactor.hpp>
+#include <gunrock/app/bc/bc_problem.hpp>
 #include <gunrock/app/bfs/bfs_enactor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
 #include <gunrock/app/cc/cc_enactor.hpp>
@@ -105,6 +109,70 @@ int main(int argc, char **argv)
     std::printf("Label Validity: ");
     num_errors += util::CompareResults(h_labels.data(), ref_labels.data(), csr.nodes, true);
     std::printf("\n");
+
+    // ---- betweenness centrality, all sources (simple_example.cu:592-672) ----
+    {
+        typedef bc::BCProblem<int, int, float, true, false> BcProblem;
+        Csr<int, float, int> fcsr(false);  // the same arrays behind the <int, float, int> graph type BC is instantiated on
+        fcsr.nodes = csr.nodes;
+        fcsr.edges = csr.edges;
+        fcsr.row_offsets = csr.row_offsets;
+        fcsr.column_indices = csr.column_indices;
+        BcProblem bc_problem;
+        bc::BCEnactor<false> bc_enactor(false);
+        bool ok = !util::GRError(bc_problem.Init(false, fcsr, 1), "BC Problem Initialization Failed", __FILE__, __LINE__);
+        util::GpuTimer bc_timer;
+        if (ok) {
+            ok = !util::GRError(bc_problem.ClearBcValues(), "BC clear failed", __FILE__, __LINE__);
+            bc_timer.Start(bc_problem.graph_slices[0]->stream);
+            for (int s = 0; ok && s < csr.nodes; ++s) {
+                ok = !util::GRError(bc_problem.Reset(s, bc_enactor.GetFrontierType(), 1.3), "BC Problem Data Reset Failed", __FILE__, __LINE__) &&
+                     !util::GRError(bc_enactor.Enact<BcProblem>(context, &bc_problem, s, 0), "BC Problem Enact Failed", __FILE__, __LINE__);
+            }
+            if (ok) ok = !util::GRError(bc_problem.ScaleBcValues(0.5f), "BC scale failed", __FILE__, __LINE__);
+            bc_timer.Stop(bc_problem.graph_slices[0]->stream);
+        }
+        std::vector<float> h_bc(csr.nodes, 0.f), ref_bc(csr.nodes, 0.f);
+        if (ok) ok = !util::GRError(bc_problem.Extract(nullptr, h_bc.data(), nullptr), "BC Problem Data Extraction Failed", __FILE__, __LINE__);
+        fcsr.row_offsets = nullptr;
+        fcsr.column_indices = nullptr;
+        if (!ok) return 1;
+        // host Brandes: BFS order + path counts forward, dependencies backward, halved like the GPU values
+        {
+            std::vector<double> acc(csr.nodes, 0.0), sigma(csr.nodes), delta(csr.nodes);
+            std::vector<int> dist(csr.nodes), order;
+            order.reserve(csr.nodes);
+            for (int s = 0; s < csr.nodes; ++s) {
+                std::fill(dist.begin(), dist.end(), -1);
+                std::fill(sigma.begin(), sigma.end(), 0.0);
+                std::fill(delta.begin(), delta.end(), 0.0);
+                order.clear();
+                dist[s] = 0;
+                sigma[s] = 1.0;
+                order.push_back(s);
+                for (size_t head = 0; head < order.size(); ++head) {
+                    const int u = order[head];
+                    for (int e = csr.row_offsets[u]; e < csr.row_offsets[u + 1]; ++e) {
+                        const int w = csr.column_indices[e];
+                        if (dist[w] < 0) { dist[w] = dist[u] + 1; order.push_back(w); }
+                        if (dist[w] == dist[u] + 1) sigma[w] += sigma[u];
+                    }
+                }
+                for (size_t i = order.size(); i-- > 1;) {
+                    const int w = order[i];
+                    for (int e = csr.row_offsets[w]; e < csr.row_offsets[w + 1]; ++e) {
+                        const int u = csr.column_indices[e];  // (undirected graph: predecessors are among the neighbours)
+                        if (dist[u] == dist[w] - 1) delta[u] += sigma[u] / sigma[w] * (1.0 + delta[w]);
+                    }
+                    acc[w] += delta[w];
+                }
+            }
+            for (int v = 0; v < csr.nodes; ++v) ref_bc[v] = static_cast<float>(0.5 * acc[v]);
+        }
+        std::printf("Validity BC Value: ");
+        num_errors += util::CompareResults(h_bc.data(), ref_bc.data(), csr.nodes, true);
+        std::printf("\nGPU BC finished in %lf msec.\n", bc_timer.ElapsedMillis());
+    }
 
     if (num_errors == 0) std::printf("\nTEST PASSED\n");
     else std::printf("\nTEST FAILED: %d errors\n", num_errors);

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_binned_min_edges": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "grx_bfs_set_cooperative_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_head_pass": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_bfs_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -321,6 +322,10 @@ class BfsProblem:
         _check(lib().grx_bfs_set_binned_min_edges(self._h, int(min_edges)), "grx_bfs_set_binned_min_edges")
         return self
 
+    def set_cooperative_launch(self, on=True):
+        _check(lib().grx_bfs_set_cooperative_launch(self._h, int(bool(on))), "grx_bfs_set_cooperative_launch")
+        return self
+
     def set_persistent_limit(self, edge_limit):
         _check(lib().grx_bfs_set_persistent_limit(self._h, int(edge_limit)), "grx_bfs_set_persistent_limit")
         return self
@@ -501,18 +506,12 @@ def gunrock_bc(nodes, row_offsets, col_indices, src=-1, queue_size=1.0, src_mode
 
 
 def gunrock_pr(nodes, row_offsets, col_indices, src=-1, delta=0.85, error=0.01, max_iter=20, top_nodes=0, src_mode=SRC_MANUALLY,
-               col_offsets=None, row_indices=None, device=0):
+               device=0):
     """Call gunrock_pr_func as reference shared_lib_tests/test_pr.c does; returns (node_ids, page_rank) in descending rank order
-    (top_nodes entries, all of them when top_nodes <= 0).  col_offsets / row_indices: the graph's CSC, when the caller has it."""
+    (top_nodes entries, all of them when top_nodes <= 0)."""
     ro = np.ascontiguousarray(row_offsets, dtype=np.int32)
     ci = np.ascontiguousarray(col_indices, dtype=np.int32)
     gin = _graph_struct(nodes, ro, ci)
-    keep = []
-    if col_offsets is not None and row_indices is not None:
-        co = np.ascontiguousarray(col_offsets, dtype=np.int32)
-        ri = np.ascontiguousarray(row_indices, dtype=np.int32)
-        gin.col_offsets, gin.row_indices = co.ctypes.data, ri.ctypes.data
-        keep = [co, ri]
     gout = GunrockGraph()
     cfg = GunrockConfig()
     cfg.src_node, cfg.device, cfg.src_mode = src, device, src_mode
@@ -522,7 +521,6 @@ def gunrock_pr(nodes, row_offsets, col_indices, src=-1, delta=0.85, error=0.01, 
     ranks = np.empty(max(count, 1), dtype=np.float32)
     dt = GunrockDataType(VTXID_INT, SIZET_INT, VALUE_FLOAT)
     lib().gunrock_pr_func(C.byref(gout), ids.ctypes.data_as(C.c_void_p), ranks.ctypes.data_as(C.c_void_p), C.byref(gin), cfg, dt)
-    del keep
     return ids[:count], ranks[:count]
 
 

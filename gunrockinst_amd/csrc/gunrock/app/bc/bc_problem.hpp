@@ -88,6 +88,7 @@ struct BCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         GR_CHECK(hipMalloc(&ds->d_ebc_values, sizeof(Value) * m), "BCProblem hipMalloc d_ebc_values failed");
         GR_CHECK(hipMemset(ds->d_bc_values, 0, sizeof(Value) * n), "BCProblem hipMemset failed");
         GR_CHECK(hipMemset(ds->d_ebc_values, 0, sizeof(Value) * m), "BCProblem hipMemset failed");
+        GR_CHECK(hipDeviceSynchronize(), "BCProblem sync failed");  // (null-stream memsets: the problem's stream is not ordered behind them)
         return retval;
     }
 

@@ -139,7 +139,7 @@ class BFSEnactor : public EnactorBase {
             p.unexplored_edges = unexplored_edges;
             p.switch_factor = switch_factor;
             if ((retval = oprtr::advance::LaunchPersistentLevels<PersistentPolicy, BFSProblem, BfsFunctor>(
-                     p, *problem->data_slices[0], cu_count, static_cast<int>(grid), stream)))
+                     p, *problem->data_slices[0], cu_count, static_cast<int>(grid), stream, problem->cooperative_launch)))
                 return retval;
         } else if ((retval = oprtr::advance::LaunchTailLevels<TailPolicy, BFSProblem, BfsFunctor>(t, *problem->data_slices[0],
                                                                                                    stream)))
@@ -182,6 +182,7 @@ class BFSEnactor : public EnactorBase {
         unsigned queue_length = problem->SourceDegree() > 0 ? 1u : 0u;
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
         if ((retval = work_progress.ResetWithTail(0, queue_length, queue_edges, stream))) return retval;
+        if (INSTRUMENT && (retval = DutyBegin(stream))) return retval;
 
 #ifndef GRX_CONV_GRID_MULT
 #define GRX_CONV_GRID_MULT 2
@@ -216,6 +217,7 @@ class BFSEnactor : public EnactorBase {
             bargs.heads_only = heads_only;
             bargs.d_never = reinterpret_cast<const unsigned long long *>(ds->d_never_mask);
             bargs.d_head_base = ds->d_head_base;
+            bargs.d_duty = INSTRUMENT ? DutySlot() : nullptr;
             const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
             long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
             // nearly finished search: few vertices can still be unvisited -> the compacting sweep (bottom_up.hpp)
@@ -262,6 +264,7 @@ class BFSEnactor : public EnactorBase {
         // count-only top-down advance over the current queue: unvisited destinations get their d_fresh byte set
         auto launch_count_only = [&](oprtr::advance::AdvanceArgs<VertexId, SizeT> args) -> hipError_t {
             ds->lite = 1;
+            if (INSTRUMENT && !args.d_duty) args.d_duty = DutySlot();
             args.d_tail_out = nullptr;  // the advance's own count includes duplicates: not wanted
             hipError_t rc = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor, true, true>(args, *ds, max_grid_size, stream,
                                                                                                               oprtr::advance::V2V);
@@ -434,6 +437,7 @@ class BFSEnactor : public EnactorBase {
                 args.d_tail_out = work_progress.d_tail + ((iteration + 1) & 3);
                 args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
                 args.d_overflow = work_progress.d_overflow;
+                args.d_duty = INSTRUMENT ? DutySlot() : nullptr;
                 // "Count-only" top-down level: when the search is about to turn bottom-up, the level's discoveries are needed
                 // only as a bitmap (visited now XOR visited before), so the frontier writer (row-offset gather, 12-byte queue
                 // entries) and the scattered label stores are skipped; the bottom-up sweep that follows labels them in order.
@@ -503,6 +507,7 @@ class BFSEnactor : public EnactorBase {
         }
         enactor_stats.iteration = iteration;
         if (retval) return retval;
+        if (INSTRUMENT && (retval = DutyCollect(stream))) return retval;
 
         // (the loop's last read-back followed its last kernel, and SetTail cleared the flag of the previous search)
         const bool overflow = work_progress.OverflowAtLastSync();

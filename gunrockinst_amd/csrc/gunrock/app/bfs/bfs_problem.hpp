@@ -160,6 +160,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // (FreshToBitmapKernel + BitmapToQueueKernel) that labels, dedupes and enqueues.  0 = never.
     long long binned_min_edges = 1ll << 23;
     oprtr::advance::BinPoolStorage<VertexId> bin_pool;
+    bool cooperative_launch = false;  // persistent levels kernel through hipLaunchCooperativeKernel (launch-time residency check)
     int persistent_edge_limit = 1 << 20;  // ... and up to this many inside the persistent multi-workgroup kernel (0 = off)
     int tail_edge_limit = 8192;  // levels with at most this many edge slots run inside the single-workgroup tail kernel
 
@@ -215,6 +216,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             const size_t bytes = (static_cast<size_t>(this->nodes) + 1023) / 1024 * 1024 + 1024;  // FreshToBitmapKernel reads 1 KiB steps
             GR_CHECK(hipMalloc(&ds->d_fresh, bytes), "BFSProblem hipMalloc d_fresh failed");
             GR_CHECK(hipMemset(ds->d_fresh, 0, bytes), "BFSProblem hipMemset d_fresh failed");  // levels leave it zero again
+            GR_CHECK(hipDeviceSynchronize(), "BFSProblem sync failed");  // (null-stream memset: the problem's stream is not ordered behind it)
         }
         if (!ds->d_inv_heads)
             GR_CHECK(hipMalloc(&ds->d_inv_heads, sizeof(int2) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)),
@@ -280,6 +282,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             const size_t bytes = (static_cast<size_t>(this->nodes) + 1023) / 1024 * 1024 + 1024;  // FreshToBitmapKernel reads 1 KiB steps
             GR_CHECK(hipMalloc(&ds->d_fresh, bytes), "BFSProblem hipMalloc d_fresh failed");
             GR_CHECK(hipMemset(ds->d_fresh, 0, bytes), "BFSProblem hipMemset d_fresh failed");  // levels leave it zero again
+            GR_CHECK(hipDeviceSynchronize(), "BFSProblem sync failed");  // (null-stream memset: the problem's stream is not ordered behind it)
         }
         if (!ds->d_frontier_mask[0])
             GR_CHECK(hipMalloc(&ds->d_frontier_mask[0], sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),

@@ -14,6 +14,7 @@
 #include <gunrock/app/problem_base.hpp>
 #include <gunrock/util/error_utils.hpp>
 #include <gunrock/util/frontier.hpp>
+#include <gunrock/util/kernel_runtime_stats.hpp>
 
 namespace gunrock {
 namespace app {
@@ -50,12 +51,17 @@ class EnactorBase {
     EnactorStats enactor_stats;
     util::WorkProgress work_progress;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // INSTRUMENT: brackets one operator launch
+    // INSTRUMENT: runtime-stamp words of the operator launches of one Enact (KernelRuntimeStats role)
+    static constexpr int kDutyLaunches = 4096;
+    unsigned long long *d_duty = nullptr;
+    int duty_used = 0;
 
     EnactorBase(FrontierType ft, bool debug) : frontier_type(ft), DEBUG(debug) {}
 
     virtual ~EnactorBase()
     {
         work_progress.Release();
+        if (d_duty) util::GRError(hipFree(d_duty), "EnactorBase hipFree failed", __FILE__, __LINE__);
         if (ev_begin) util::GRError(hipEventDestroy(ev_begin), "EnactorBase hipEventDestroy failed", __FILE__, __LINE__);
         if (ev_end) util::GRError(hipEventDestroy(ev_end), "EnactorBase hipEventDestroy failed", __FILE__, __LINE__);
     }
@@ -76,6 +82,38 @@ class EnactorBase {
         return util::GRError(hipEventRecord(ev_end, stream), "EnactorBase hipEventRecord failed", __FILE__, __LINE__);
     }
     // call after the stream has been synchronised
+    // start of an instrumented Enact: clear the stamp words
+    hipError_t DutyBegin(hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        if (!d_duty) GR_CHECK(hipMalloc(&d_duty, sizeof(unsigned long long) * util::kDutyWords * kDutyLaunches), "EnactorBase hipMalloc failed");
+        duty_used = 0;
+        enactor_stats.total_runtimes = 0;
+        enactor_stats.total_lifetimes = 0;
+        return util::GRError(hipMemsetAsync(d_duty, 0, sizeof(unsigned long long) * util::kDutyWords * kDutyLaunches, stream),
+                             "EnactorBase memset failed", __FILE__, __LINE__);
+    }
+    // stamp words for the next operator launch (nullptr once the table is full: that launch goes unmeasured)
+    unsigned long long *DutySlot()
+    {
+        if (!d_duty || duty_used >= kDutyLaunches) return nullptr;
+        return d_duty + static_cast<size_t>(util::kDutyWords) * duty_used++;
+    }
+    // end of Enact: total_runtimes = sum of workgroup runtimes, total_lifetimes = sum over launches of (longest runtime x
+    // workgroups), so that total_runtimes / total_lifetimes is the reference's "avg CTA duty" (kernel_runtime_stats.cuh:226-279)
+    hipError_t DutyCollect(hipStream_t stream)
+    {
+        hipError_t retval = hipSuccess;
+        if (!d_duty || duty_used == 0) return retval;
+        std::vector<unsigned long long> h(static_cast<size_t>(util::kDutyWords) * duty_used);
+        GR_CHECK(hipMemcpyAsync(h.data(), d_duty, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, stream), "EnactorBase copy failed");
+        GR_CHECK(hipStreamSynchronize(stream), "EnactorBase sync failed");
+        for (int i = 0; i < duty_used; ++i) {
+            enactor_stats.total_runtimes += static_cast<double>(h[3 * i]);
+            enactor_stats.total_lifetimes += static_cast<double>(h[3 * i + 1]) * static_cast<double>(h[3 * i + 2]);
+        }
+        return retval;
+    }
     void InstrumentCollect(long long frontier = 0, long long edges = 0, int kind = 0)
     {
         float ms = 0;

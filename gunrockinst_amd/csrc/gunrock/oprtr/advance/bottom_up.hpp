@@ -24,6 +24,7 @@
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
 #include <gunrock/util/frontier.hpp>
+#include <gunrock/util/kernel_runtime_stats.hpp>
 
 namespace gunrock {
 namespace oprtr {
@@ -162,6 +163,7 @@ struct BottomUpArgs {
     int *d_overflow = nullptr;
     int heads_only = 0;                     // 1: probe the adjacency heads and stop (no CSR walk): a cheap first cut of a level
     unsigned long long *d_wide = nullptr;   // when set, workgroup counts go to WorkProgress's wide tail instead of d_tail_out
+    unsigned long long *d_duty = nullptr;   // INSTRUMENT: this launch's runtime-stamp words (util/kernel_runtime_stats.hpp)
 };
 
 // 64-vertex bitmap words one wave takes per step of the bottom-up sweep (launch code sizes the grid from it)
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
     constexpr int WAVES = THREADS / util::kWaveSize;
     constexpr int STEP_WORDS = kBottomUpStepWords;  // bitmap words (x64 vertices) a wave takes per step; lanes 0..STEP_WORDS-1 own one word each
     __shared__ unsigned long long s_total[WAVES];
+    util::DutyStamp duty(a.d_duty);
 
     const int tid = threadIdx.x;
     const unsigned lane = util::LaneId();
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
     typedef FrontierWriter<THREADS, EMIT_QUEUE ? CAPACITY : THREADS, VertexId, SizeT> Writer;
     __shared__ unsigned long long s_total[WAVES];
     __shared__ unsigned s_found[WAVES][CHUNK_WORDS * 2];  // found bits of the wave's current chunk, 32-bit halves
+    util::DutyStamp duty(a.d_duty);
     __shared__ typename Writer::Storage s_writer;
     if (EMIT_QUEUE) {
         Writer::Init(s_writer);

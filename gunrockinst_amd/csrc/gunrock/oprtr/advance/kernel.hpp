@@ -31,6 +31,7 @@
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
 #include <gunrock/util/frontier.hpp>
+#include <gunrock/util/kernel_runtime_stats.hpp>
 
 namespace gunrock {
 namespace oprtr {
@@ -68,6 +69,7 @@ struct AdvanceArgs {
     unsigned long long *d_tail_clear;  // ring slot to zero for the step after next
     int *d_overflow;
     BinPool<VertexId> bins;            // BINNED advance only (binned.hpp): where phase 1 hands its survivors
+    unsigned long long *d_duty = nullptr;     // INSTRUMENT: this launch's runtime-stamp words (util/kernel_runtime_stats.hpp)
     const void *d_value_to_reduce = nullptr;  // reducing advance only (LaunchReduce): values indexed by vertex / by edge ...
     void *d_reduced_value = nullptr;          // ... and the per-frontier-entry results
 };
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void LoadBalancedKernel(
     typedef AdvanceShared<KernelPolicy, VertexId, SizeT, !COUNT_ONLY> Shared;
     typedef typename Shared::Writer Writer;
     __shared__ Shared sh;
+    util::DutyStamp duty(a.d_duty);
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.d_tail_clear) *a.d_tail_clear = 0ull;
     if constexpr (!COUNT_ONLY) Writer::Init(sh.writer);
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void BinnedExpandKernel(
     typedef AdvanceShared<KernelPolicy, VertexId, SizeT, false> Shared;
     typedef Binner<KernelPolicy::THREADS, KernelPolicy::ITEMS, VertexId, ProblemData::MARK_PREDECESSORS> Bins;
     __shared__ Shared sh;
+    util::DutyStamp duty(a.d_duty);
     unsigned tile_tag;
     InitOwnerMarks<KernelPolicy>(sh, tile_tag);
 
@@ -838,9 +842,13 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
     }
 }
 
+// cooperative: launch through hipLaunchCooperativeKernel, whose launch-time check rejects a grid beyond the occupancy query
+// (+15-19 us of host time per launch on MI355X; residency itself is the same as a plain launch's, so it is off by default and
+// the barrier's timeout word stays the run-time safety net against CUs taken by another stream or process).
 template <typename KernelPolicy, typename ProblemData, typename Functor>
 hipError_t LaunchPersistentLevels(const PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
-                                  const typename ProblemData::DataSlice &slice, int cu_count, int grid_hint, hipStream_t stream)
+                                  const typename ProblemData::DataSlice &slice, int cu_count, int grid_hint, hipStream_t stream,
+                                  bool cooperative = false)
 {
     int grid = util::ResidentGrid(PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>, KernelPolicy::THREADS);
     if (grid > cu_count) grid = cu_count;  // one workgroup per CU: every one of them is resident
@@ -848,6 +856,14 @@ hipError_t LaunchPersistentLevels(const PersistentArgs<typename ProblemData::Ver
     if (grid < 1) grid = 1;
     // contract: barrier counter and timeout word (adjacent: WorkProgress slot 7) are ZERO at launch -- WorkProgress::Reset
     // zeroes them at the start of an Enact and every read-back (PublishKernel) re-arms them after mirroring
+    if (cooperative) {
+        PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a = args;
+        typename ProblemData::DataSlice s = slice;
+        void *params[] = {&a, &s};
+        return util::GRError(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>),
+                                                        dim3(grid), dim3(KernelPolicy::THREADS), params, 0, stream),
+                             "advance::PersistentLevelsKernel cooperative launch failed", __FILE__, __LINE__);
+    }
     hipLaunchKernelGGL((PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(grid), dim3(KernelPolicy::THREADS), 0,
                        stream, args, slice);
     return util::GRError("advance::PersistentLevelsKernel launch failed", __FILE__, __LINE__);

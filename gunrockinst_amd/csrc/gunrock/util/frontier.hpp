@@ -143,7 +143,13 @@ struct WorkProgress {
         GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
         GR_CHECK(hipMemset(d_sums, 0, sizeof(unsigned long long) * 2), "WorkProgress memset failed");
         GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress hipMalloc d_wide failed");
-        return Reset(0);
+        // Blocking clears: the enactors work on non-blocking streams, which are NOT ordered behind the null stream -- an
+        // asynchronous clear issued here could land after the first search's seed (seen: a search that found nothing).
+        GR_CHECK(hipMemset(d_tail, 0, sizeof(unsigned long long) * kSlots), "WorkProgress memset failed");
+        GR_CHECK(hipMemset(d_overflow, 0, sizeof(int)), "WorkProgress memset failed");
+        GR_CHECK(hipMemset(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress memset failed");
+        GR_CHECK(hipDeviceSynchronize(), "WorkProgress init sync failed");
+        return retval;
     }
 
     hipError_t Reset(hipStream_t stream)

@@ -97,5 +97,38 @@ int CompareResults(const T *computed, const T *reference, SizeT len, bool verbos
     return flag;
 }
 
+// Floating-point form, with the reference's tolerance (gunrock/util/test_utils.cuh:360-405): a value below 0.01 in
+// magnitude may differ by 0.05 absolutely, any other by 5 % relatively.
+template <typename SizeT>
+int CompareResults(const float *computed, const float *reference, SizeT len, bool verbose = true)
+{
+    const float threshold = 0.05f;
+    int flag = 0;
+    for (SizeT i = 0; i < len; ++i) {
+        bool is_right = true;
+        const float ref = reference[i], got = computed[i];
+        const float mag = ref < 0 ? -ref : ref;
+        const float diff = got > ref ? got - ref : ref - got;
+        if (mag < 0.01f) is_right = diff <= threshold;
+        else is_right = diff <= threshold * mag;
+        if (is_right) continue;
+        if (flag == 0) {
+            std::printf("\nINCORRECT: [%lu]: %f != %f", (unsigned long)i, got, ref);
+            if (verbose) {
+                const SizeT lo = i >= 5 ? i - 5 : 0, hi = i + 5 < len ? i + 5 : len;
+                std::printf("\nresult[...");
+                for (SizeT j = lo; j < hi; ++j) std::printf("%f, ", computed[j]);
+                std::printf("...]\nreference[...");
+                for (SizeT j = lo; j < hi; ++j) std::printf("%f, ", reference[j]);
+                std::printf("...]");
+            }
+        }
+        ++flag;
+    }
+    std::printf("\n");
+    if (flag == 0) std::printf("CORRECT");
+    return flag;
+}
+
 }  // namespace util
 }  // namespace gunrock

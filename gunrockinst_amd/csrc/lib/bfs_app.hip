@@ -13,6 +13,7 @@
 
 #include <gunrock/app/bfs/bfs_enactor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
+#include <gunrock/graphio/symmetry.hpp>
 #include <gunrock/csr.hpp>
 #include <gunrock/graphio/utils.hpp>
 #include <gunrock/util/context.hpp>
@@ -30,8 +31,10 @@ struct BfsRunner {
     virtual hipError_t Init(const Csr<int, int, int> &g) = 0;
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
+    virtual hipError_t AutoInverse(bool &enabled) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual void SetPersistentLimit(int limit) = 0;
+    virtual void SetCooperativeLaunch(bool on) = 0;
     virtual void SetBinnedMinEdges(long long min_edges) = 0;
     virtual void SetHeadPass(int min_edges, int max_edges) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
@@ -71,7 +74,27 @@ struct BfsRunnerT : BfsRunner {
         if (!d_iro || !d_ici) return problem.InverseIsSelf(alpha, beta);
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
     }
+    // One-shot callers (gunrock_bfs_func) hand over host arrays only.  Direction-optimizing traversal needs the in-neighbour
+    // lists: the CSR itself when every edge has its mirror (checked on the device).  The CSC fields of GunrockGraph are NOT
+    // read: the reference's BFS ignores them and its own test leaves them uninitialised (shared_lib_tests/test_bfs.c:36-42),
+    // so a drop-in must not dereference them.  A directed graph stays top-down.
+    hipError_t AutoInverse(bool &enabled) override
+    {
+        hipError_t retval = hipSuccess;
+        enabled = false;
+        if (!problem.data_slices || problem.nodes <= 0 || problem.edges <= 0) return retval;
+        GraphSlice<int, int, int> *gs = problem.graph_slices[0];
+        bool symmetric = false;
+        GR_CHECK(graphio::DeviceIsSymmetric(problem.nodes, problem.edges, gs->d_row_offsets, gs->d_column_indices, gs->stream, symmetric),
+                 "BFS symmetry check failed");
+        if (symmetric) {
+            GR_CHECK(problem.InverseIsSelf(), "BFS InverseIsSelf failed");
+            enabled = true;
+        }
+        return retval;
+    }
     void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
+    void SetCooperativeLaunch(bool on) override { problem.cooperative_launch = on; }
     void SetBinnedMinEdges(long long min_edges) override { problem.binned_min_edges = min_edges; }
     void SetHeadPass(int min_edges, int max_edges) override
     {
@@ -224,6 +247,13 @@ int grx_bfs_set_binned_min_edges(grx_bfs *p, long long min_edges)
     return 0;
 }
 
+int grx_bfs_set_cooperative_launch(grx_bfs *p, int on)
+{
+    if (!p || !p->runner) return 1;
+    p->runner->SetCooperativeLaunch(on != 0);
+    return 0;
+}
+
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit)
 {
     if (!p || !p->runner || edge_limit < 0) return 1;
@@ -319,13 +349,20 @@ void gunrock_bfs_func(struct GunrockGraph *graph_out, const struct GunrockGraph 
     BfsRunner *runner = MakeRunner(configs.mark_pred, configs.idempotence, false, configs.device);
     float elapsed = 0;
     hipError_t rc = runner->Init(csr);
+    // The reference's entry point always runs its top-down enactor (bfs_app.cu:196-200).  Here a graph that is its own inverse
+    // runs direction-optimizing (the reference's separate DOBFS primitive): same labels, a fraction of the edges looked at.
+    // Small graphs stay top-down: the in-neighbour tables would cost more than the search.
+    bool dobfs = false;
+    if (!rc && csr.edges >= (1 << 16))
+        rc = util::GRError(runner->AutoInverse(dobfs), "BFS inverse graph setup failed", __FILE__, __LINE__);
     if (!rc) rc = util::GRError(runner->Reset(src, queue_sizing), "BFS Problem Data Reset Failed", __FILE__, __LINE__);
-    if (!rc) rc = util::GRError(runner->Enact(src, 0, 0, &elapsed), "BFS Problem Enact Failed", __FILE__, __LINE__);
+    if (!rc) rc = util::GRError(runner->Enact(src, 0, dobfs ? 2 : 0, &elapsed), "BFS Problem Enact Failed", __FILE__, __LINE__);
     long long queued = 0, depth = 0, launches = 0;
     double duty = 0, kernel_ms = 0;
     runner->Stats(queued, depth, duty, launches, kernel_ms);
     if (!rc) rc = util::GRError(runner->Extract(h_labels, nullptr), "BFS Problem Data Extraction Failed", __FILE__, __LINE__);
     graph_out->node_values = h_labels;  // caller frees (bfs_app.cu:211)
+    if (!rc && dobfs) std::printf("[GPU Breadth-first search] symmetric input: direction-optimizing traversal.\n");
     if (!rc) DisplayStats("GPU Breadth-first search", src, h_labels, csr, elapsed, depth, queued, duty);
     delete runner;
     csr.row_offsets = nullptr;

@@ -99,6 +99,10 @@ int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, i
  * kernel (one resident workgroup per CU, grid barrier between levels; 0 disables).  This is what the reference's
  * traversal_mode 1 (TWC advance for low-degree, high-diameter graphs, tests/bfs/test_bfs.cu:563-566) is for. */
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit);
+/* Launch that kernel with hipLaunchCooperativeKernel (the runtime then refuses a grid that exceeds the occupancy query at
+ * launch time; costs ~15-19 us of host time per launch).  Off by default: a plain launch of the same grid has the same
+ * residency, and the grid barrier's timeout word reports a lost co-residency at run time either way. */
+int grx_bfs_set_cooperative_launch(grx_bfs *p, int on);
 /* Top-down levels with at least `min_edges` frontier edges run as a destination-binned advance: expand + status screen,
  * claims on the destination's owner XCD without atomics, then a vertex-ordered closing sweep that labels and enqueues
  * (0 = never; default 2^23).  This replaces the per-edge atomicCAS of the reference's functor (bfs_functor.cuh:56-58) on the

@@ -259,6 +259,7 @@ def test_persistent_levels_kernel_parity(persistent_limit, tail_limit):
             p.set_inverse_graph()
             p.set_tuning(tail_edge_limit=tail_limit)
             p.set_persistent_limit(persistent_limit)
+            p.set_cooperative_launch(mark_pred)             # half of the runs through hipLaunchCooperativeKernel
             for src in srcs:
                 for mode in (0, 1, 2):
                     p.reset(int(src))
@@ -341,3 +342,32 @@ def test_binned_advance_parity(min_edges, tail_limit):
                     labels, preds = p.extract()
                     _check(g, int(src), labels, preds, p.stats())
             p.close()
+
+
+def test_c_abi_entry_point_picks_direction_optimizing_on_symmetric_input(capfd):
+    # gunrock_bfs_func on a graph that is its own inverse runs the direction-optimizing schedule (the reference's entry point is
+    # top-down only, bfs_app.cu:196-200); a directed graph, or a small one, stays top-down.  Labels are the oracle's either way.
+    for scale, und, expect in [(16, True, True), (16, False, False), (10, True, False)]:
+        g = o.rmat_seeded(scale, 8 << scale, undirected=und)
+        src, _ = o.highest_degree_node(g)
+        for mark_pred, idem in [(False, True), (True, False)]:
+            capfd.readouterr()
+            labels = ga.gunrock_bfs(g.nodes, g.row_offsets, g.col_indices, src=int(src), mark_pred=mark_pred, idempotence=idem)
+            ref, _, _ = o.bfs(g, int(src))
+            assert np.array_equal(labels, ref)
+            out = capfd.readouterr().out
+            assert ("direction-optimizing traversal" in out) == expect, out
+
+
+def test_instrumented_enactor_reports_cta_duty():
+    # KernelRuntimeStats role (reference kernel_runtime_stats.cuh:226-279, bfs_enactor.cuh:173-186): avg duty = sum of
+    # workgroup runtimes / (longest runtime x workgroups), over the operator launches of the last Enact; 0 when not instrumented
+    g = o.rmat_seeded(16, 8 << 16)
+    src, _ = o.highest_degree_node(g)
+    for mode in (0, 2):
+        labels, _, st, _ = _run(g, int(src), False, True, instrument=True, mode=mode)
+        ref, _, _ = o.bfs(g, int(src))
+        assert np.array_equal(labels, ref)
+        assert 0.0 < st["avg_duty"] <= 1.0, st
+    _, _, st, _ = _run(g, int(src), False, True, instrument=False)
+    assert st["avg_duty"] == 0.0

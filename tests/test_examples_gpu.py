@@ -35,6 +35,7 @@ def test_simple_example_prints_test_passed():
     out = _run([os.path.join(ROOT, "examples", "simple_example"), "market", os.path.join(ROOT, "tests", "golden", "bips98_606.mtx")])
     assert out.returncode == 0, out.stdout + out.stderr
     assert "TEST PASSED" in out.stdout and "Label Validity: \nCORRECT" in out.stdout
+    assert "Validity BC Value: \nCORRECT" in out.stdout                # third stage of the reference's example (simple_example.cu:592-672)
     assert "CPU components: 542, GPU components: 542" in out.stdout
     assert "7135 nodes, 30380 edges" in out.stdout
 

@@ -50,9 +50,6 @@ def test_fixture7_c_abi(golden, capfd):
     assert "[GPU PageRank] finished." in capfd.readouterr().out
     ids3, ranks3 = ga.gunrock_pr(7, g.row_offsets, g.col_indices, src=-1, top_nodes=3)
     _check_ranks(g, ids3, ranks3, -1, 0.85, 0.01, 20, top=3)
-    co, ri = _transpose(g)                                            # the caller's CSC is used when the struct carries one
-    ids, ranks = ga.gunrock_pr(7, g.row_offsets, g.col_indices, src=0, col_offsets=co, row_indices=ri)
-    _check_ranks(g, ids, ranks, 0, 0.85, 0.01, 20)
 
 
 def test_topk_known_answer(golden):
