@@ -491,6 +491,8 @@ def bench_sssp(args, torch, ga, devgraph, device_index):
     sources = [src0] + devgraph.seeded_sources(ro, 8, args.seed)
     p = ga.SsspProblem(mark_pred=False, instrument=False, device=device_index)
     p.init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+    if os.environ.get("GUNROCK_SSSP_PULL") == "1":   # (off: on this workload no level's frontier holds 3/4 of the edges)
+        p.set_inverse_graph()         # weighted in-neighbour lists (transpose on the device): dense levels relax by pulling
     steps = max(1, min(args.steps, len(sources)))
     for k in range(min(args.warmup, 2)):
         p.reset(sources[k % len(sources)]); p.enact(sources[k % len(sources)])

@@ -121,6 +121,8 @@ _SIGNATURES = {
     "grx_sssp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "grx_sssp_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p, C.POINTER(C.c_uint32), C.c_int]),
     "grx_sssp_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "grx_sssp_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
+    "grx_sssp_pull_levels": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "grx_sssp_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_sssp_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "grx_sssp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
@@ -678,6 +680,17 @@ class SsspProblem:
         _check(lib().grx_sssp_init_device(self._h, nodes, edges, C.c_void_p(d_row_offsets), C.c_void_p(d_col_indices),
                                           C.c_void_p(d_weights), float(delta)), "SSSPProblem::Init(device)")
         return self
+
+    def set_inverse_graph(self, d_inv_row_offsets=None, d_inv_col_indices=None, d_inv_weights=None, pull_min_edges=-1):
+        """Enable pull relaxation of dense levels; no arrays = build the weighted transpose on the device."""
+        _check(lib().grx_sssp_set_inverse_graph(self._h, C.c_void_p(d_inv_row_offsets), C.c_void_p(d_inv_col_indices),
+                                                C.c_void_p(d_inv_weights), int(pull_min_edges)), "SSSPProblem::SetInverseGraph")
+        return self
+
+    def pull_levels(self):
+        n = C.c_longlong()
+        _check(lib().grx_sssp_pull_levels(self._h, C.byref(n)), "grx_sssp_pull_levels")
+        return int(n.value)
 
     def reset(self, src, queue_sizing=1.0):
         _check(lib().grx_sssp_reset(self._h, int(src), float(queue_sizing)), "SSSPProblem::Reset")

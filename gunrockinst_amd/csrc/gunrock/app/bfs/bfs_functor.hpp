@@ -45,7 +45,13 @@ struct BFSFunctor {
         const unsigned *base = flags ? reinterpret_cast<const unsigned *>(problem->d_fresh) : problem->d_visited_mask;
         const unsigned index = static_cast<unsigned>(d_id) >> (flags ? 2 : 5);
         const unsigned shift = flags ? (static_cast<unsigned>(d_id) & 3u) * 8u : (static_cast<unsigned>(d_id) & 31u);
+#if defined(GRX_SCREEN_SC1)
         const unsigned word = __hip_atomic_load(base + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        // lite == 1 / 3 (count-only level, phase 1 of a binned level): nothing writes the bitmap during the launch -> plain load
+        const bool cached = problem->lite == 1 || problem->lite == 3;
+        const unsigned word = cached ? base[index] : __hip_atomic_load(base + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         return ((word >> shift) & (flags ? 0xFFu : 1u)) == 0;  // (bitmap: stale-tolerant, a miss only costs an atomic)
     }
 
@@ -64,6 +70,23 @@ struct BFSFunctor {
         unsigned *word = problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5);
         const unsigned bit = 1u << (d_id & 31);
         return (atomicOr(word, bit) & bit) == 0;          // exactly one winner per vertex
+    }
+
+    // CondEdge in two halves (advance hook): all claims of a tile are issued before any returned word is examined.
+    // Token: the bitmap word as the atomicOr returned it, untouched (a test here would make the wave wait for the atomic
+    // inside the branch that guards the call); lite levels claim nothing and return a clear word.
+    static __device__ __forceinline__ unsigned IssueEdge(VertexId /*s_id*/, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
+                                                         VertexId /*e_id_in*/ = 0)
+    {
+        if (problem->lite) {
+            problem->d_fresh[d_id] = 1;
+            return 0u;
+        }
+        return atomicOr(problem->d_visited_mask + (static_cast<unsigned>(d_id) >> 5), 1u << (d_id & 31));
+    }
+    static __device__ __forceinline__ bool ResolveEdge(unsigned token, VertexId, VertexId d_id, DataSlice *, VertexId = 0, VertexId = 0)
+    {
+        return (token & (1u << (d_id & 31))) == 0;  // the bit was clear: this edge claimed the vertex
     }
 
     static __device__ __forceinline__ void ApplyEdge(VertexId s_id, VertexId d_id, DataSlice *problem,

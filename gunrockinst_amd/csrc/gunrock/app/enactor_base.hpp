@@ -52,7 +52,7 @@ class EnactorBase {
     util::WorkProgress work_progress;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // INSTRUMENT: brackets one operator launch
     // INSTRUMENT: runtime-stamp words of the operator launches of one Enact (KernelRuntimeStats role)
-    static constexpr int kDutyLaunches = 4096;
+    static constexpr int kDutyLaunches = 512;
     unsigned long long *d_duty = nullptr;
     int duty_used = 0;
 
@@ -109,8 +109,15 @@ class EnactorBase {
         GR_CHECK(hipMemcpyAsync(h.data(), d_duty, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, stream), "EnactorBase copy failed");
         GR_CHECK(hipStreamSynchronize(stream), "EnactorBase sync failed");
         for (int i = 0; i < duty_used; ++i) {
-            enactor_stats.total_runtimes += static_cast<double>(h[3 * i]);
-            enactor_stats.total_lifetimes += static_cast<double>(h[3 * i + 1]) * static_cast<double>(h[3 * i + 2]);
+            double sum = 0, longest = 0, groups = 0;
+            for (int l = 0; l < util::kDutyLines; ++l) {
+                const unsigned long long *w = h.data() + static_cast<size_t>(util::kDutyWords) * i + static_cast<size_t>(util::kDutyLineWords) * l;
+                sum += static_cast<double>(w[0]);
+                if (static_cast<double>(w[1]) > longest) longest = static_cast<double>(w[1]);
+                groups += static_cast<double>(w[2]);
+            }
+            enactor_stats.total_runtimes += sum;
+            enactor_stats.total_lifetimes += longest * groups;
         }
         return retval;
     }

@@ -18,6 +18,7 @@
 #include <gunrock/app/sssp/sssp_functor.hpp>
 #include <gunrock/app/sssp/sssp_problem.hpp>
 #include <gunrock/oprtr/advance/kernel.hpp>
+#include <gunrock/oprtr/filter/kernel.hpp>
 #include <gunrock/priority_queue/kernel.hpp>
 #include <gunrock/util/context.hpp>
 
@@ -33,6 +34,7 @@ class SSSPEnactor : public EnactorBase {
 
     long long relaxed_vertices = 0;  // vertices dequeued by advances (sum of frontier lengths)
     long long relaxed_edges = 0;     // edge slots expanded
+    long long pull_levels = 0;       // levels relaxed by pulling over the in-neighbour lists
 
     void GetStatistics(long long &total_queued, long long &search_depth, double &avg_duty)
     {
@@ -57,6 +59,9 @@ class SSSPEnactor : public EnactorBase {
         typedef typename SSSPProblem::Value Value;
         typedef SSSPFunctor<VertexId, SizeT, SSSPProblem> SsspFunctor;
         typedef PQFunctor<VertexId, SizeT, SSSPProblem> PqFunctor;
+        typedef SSSPPullFunctor<VertexId, SizeT, SSSPProblem> PullFunctor;
+        typedef typename PullFunctor::PullValue PullValue;
+        typedef oprtr::filter::KernelPolicy<256, 4, 8> FilterPolicy;
 
         hipError_t retval = hipSuccess;
         if ((retval = EnactorBase::Setup(max_grid_size, AdvancePolicy::MIN_BLOCKS, 8))) return retval;
@@ -64,6 +69,7 @@ class SSSPEnactor : public EnactorBase {
         typename SSSPProblem::DataSlice *ds = problem->data_slices[0];
         hipStream_t stream = gs->stream;
         relaxed_vertices = relaxed_edges = 0;
+        pull_levels = 0;
         if (src < 0 || src >= problem->nodes) return retval;
         if ((retval = work_progress.Reset(stream))) return retval;
 
@@ -112,8 +118,41 @@ class SSSPEnactor : public EnactorBase {
                 args.d_tail_clear = nullptr;
                 args.d_overflow = work_progress.d_overflow;
                 if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
-                if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, SSSPProblem, SsspFunctor, false>(
-                         args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
+                const bool pull = problem->HasInverse() && problem->pull_min_edges != 0 &&
+                                  static_cast<long long>(queue_edges) > problem->PullMinEdges();
+                if (pull) {
+                    // ---- dense level: every vertex takes the minimum over its in-edges of (neighbour's distance + weight), one
+                    //      reducing advance over the in-neighbour lists, no atomic per edge; then a sweep over the vertices keeps
+                    //      the improvements and hands the improved vertices to the split as the push would ----
+                    ++pull_levels;
+                    relaxed_edges += problem->inv_frontier_edges - queue_edges;  // (what was actually swept)
+                    oprtr::advance::AdvanceArgs<VertexId, SizeT> pa;
+                    pa.in = problem->inv_frontier;
+                    pa.in_len = problem->inv_frontier_len;
+                    pa.in_edges = problem->inv_frontier_edges;
+                    pa.d_row_offsets = problem->d_inv_row_offsets;
+                    pa.d_column_indices = problem->d_inv_column_indices;
+                    pa.d_tail_out = nullptr;
+                    pa.d_tail_clear = nullptr;
+                    pa.d_overflow = work_progress.d_overflow;
+                    if ((retval = oprtr::advance::LaunchReduce<AdvancePolicy, SSSPProblem, PullFunctor, oprtr::advance::VERTEX,
+                                                               oprtr::advance::MINIMUM, PullValue, true>(
+                             pa, *ds, static_cast<const PullValue *>(nullptr), static_cast<PullValue *>(ds->d_pull), max_grid_size, stream,
+                             static_cast<long long>(problem->nodes))))
+                        break;
+                    oprtr::filter::FilterArgs<VertexId, SizeT> f;
+                    f.d_in = nullptr;  // every vertex
+                    f.num_elements = problem->nodes;
+                    f.out = util::Frontier<VertexId, SizeT>();
+                    f.out.v = problem->d_candidates;
+                    f.out.capacity = problem->candidate_capacity;
+                    f.d_tail_out = d_tail + 0;
+                    f.d_tail_clear = nullptr;
+                    f.d_overflow = work_progress.d_overflow;
+                    f.d_row_offsets = gs->d_row_offsets;
+                    if ((retval = oprtr::filter::LaunchKernel<FilterPolicy, SSSPProblem, PullFunctor, false>(f, *ds, cu_count * 8, stream))) break;
+                } else if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, SSSPProblem, SsspFunctor, false>(
+                                args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;
                 if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                 if ((retval = read_tails())) break;

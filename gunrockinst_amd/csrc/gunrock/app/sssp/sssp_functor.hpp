@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace gunrock {
 namespace app {
 namespace sssp {
@@ -45,6 +47,37 @@ struct SSSPFunctor {
         return candidate < atomicMin(problem->d_labels + d_id, candidate);
     }
 
+    // CondEdge in two halves (advance hook): the atomicMin of every edge of a tile is issued before any result is examined.
+    // The token carries what the atomic returned UNTOUCHED (any arithmetic on it here would make the wave wait for the atomic
+    // inside the branch that guards the call) next to the candidate; a wrapped candidate issues nothing and cannot win.
+    struct Token {
+        unsigned candidate;
+        unsigned old_lo;            // previous distance (plain labels) ...
+        unsigned long long old_hi;  // ... or previous packed (distance, predecessor)
+    };
+    static __device__ __forceinline__ Token IssueEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId e_id = 0,
+                                                      VertexId /*e_id_in*/ = 0)
+    {
+        Token t;
+        const unsigned from = problem->Distance(s_id);
+        t.candidate = from + problem->d_weights[e_id];
+        t.old_lo = 0u;
+        t.old_hi = 0ull;
+        if (t.candidate < from) t.candidate = 0xFFFFFFFFu;  // wrapped: not a path length
+        if (t.candidate != 0xFFFFFFFFu) {
+            if (ProblemData::MARK_PATHS)
+                t.old_hi = atomicMin(problem->d_dist_pred + d_id, (static_cast<unsigned long long>(t.candidate) << 32) | static_cast<unsigned>(s_id));
+            else
+                t.old_lo = atomicMin(problem->d_labels + d_id, t.candidate);
+        }
+        return t;
+    }
+    static __device__ __forceinline__ bool ResolveEdge(const Token &t, VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0)
+    {
+        const unsigned old = ProblemData::MARK_PATHS ? static_cast<unsigned>(t.old_hi >> 32) : t.old_lo;
+        return t.candidate != 0xFFFFFFFFu && t.candidate < old;
+    }
+
     static __device__ __forceinline__ void ApplyEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0)
     {
         // the predecessor travels inside the packed atomicMin of CondEdge
@@ -52,6 +85,45 @@ struct SSSPFunctor {
 
     static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice *, unsigned = 0, SizeT = 0) { return node != -1; }
     static __device__ __forceinline__ void ApplyFilter(VertexId, DataSlice *, unsigned = 0, SizeT = 0) {}
+};
+
+// ---- pull form of a relaxation level (dense levels; sssp_enactor.hpp) ----
+// The reducing advance runs over the IN-neighbour lists: s_id = the vertex that may improve, d_id = one of its in-neighbours,
+// e_id = the in-edge (inverse-CSR position).  ReduceValue = that neighbour's distance + the edge's weight (packed with the
+// neighbour when predecessors are kept); the operator takes the MINIMUM per vertex, no atomic per edge.
+template <typename VertexId, typename SizeT, typename ProblemData>
+struct SSSPPullFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    typedef typename std::conditional<ProblemData::MARK_PATHS, unsigned long long, unsigned>::type PullValue;
+
+    static __device__ __forceinline__ bool CondEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) { return true; }
+    static __device__ __forceinline__ void ApplyEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) {}
+    static __device__ __forceinline__ PullValue ReduceValue(VertexId /*s_id*/, VertexId d_id, DataSlice *problem, VertexId e_id = 0,
+                                                            VertexId /*e_id_in*/ = 0)
+    {
+        const unsigned from = problem->Distance(d_id);
+        unsigned candidate = from + problem->d_inv_weights[e_id];
+        if (candidate < from) candidate = 0xFFFFFFFFu;  // wrapped (an unreached neighbour wraps too): not a path length
+        if (ProblemData::MARK_PATHS) return static_cast<PullValue>((static_cast<unsigned long long>(candidate) << 32) | static_cast<unsigned>(d_id));
+        return static_cast<PullValue>(candidate);
+    }
+    // filter over all vertices after the reduction: a vertex whose best pulled candidate beats its distance takes it and
+    // becomes a candidate of the near/far split, exactly like the destination of a successful push
+    static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice *problem, int /*v*/ = 0, SizeT /*nid*/ = 0)
+    {
+        const PullValue best = static_cast<const PullValue *>(problem->d_pull)[node];
+        if (ProblemData::MARK_PATHS) {
+            const unsigned candidate = static_cast<unsigned>(static_cast<unsigned long long>(best) >> 32);
+            if (candidate == 0xFFFFFFFFu || candidate >= problem->Distance(node)) return false;
+            problem->d_dist_pred[node] = static_cast<unsigned long long>(best);
+            return true;
+        }
+        const unsigned candidate = static_cast<unsigned>(best);
+        if (candidate == 0xFFFFFFFFu || candidate >= problem->d_labels[node]) return false;
+        problem->d_labels[node] = candidate;
+        return true;
+    }
+    static __device__ __forceinline__ void ApplyFilter(VertexId, DataSlice *, int = 0, SizeT = 0) {}
 };
 
 template <typename VertexId, typename SizeT, typename ProblemData>

@@ -20,6 +20,7 @@
 #include <climits>
 
 #include <gunrock/app/problem_base.hpp>
+#include <gunrock/graphio/device_sort.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
 namespace gunrock {
@@ -45,6 +46,29 @@ static __global__ void SplitDistPredKernel(const unsigned long long *d_dist_pred
     }
 }
 
+// frontier of every vertex that has in-edges, in vertex order: vertices without in-edges own no slots, so the exclusive degree
+// prefix of entry v IS inv_row_offsets[v]
+template <typename SizeT>
+__global__ void HasInEdgesKernel(const SizeT *d_inv_row_offsets, long long nodes, unsigned *d_flags)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v <= nodes; v += stride)
+        d_flags[v] = (v < nodes && d_inv_row_offsets[v + 1] > d_inv_row_offsets[v]) ? 1u : 0u;
+}
+template <typename VertexId, typename SizeT>
+__global__ void InFrontierKernel(const SizeT *d_inv_row_offsets, const unsigned *d_flags, const unsigned *d_pos, long long nodes,
+                                 VertexId *d_v, SizeT *d_row_start, SizeT *d_scan)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v < nodes; v += stride) {
+        if (!d_flags[v]) continue;
+        const unsigned i = d_pos[v];
+        d_v[i] = static_cast<VertexId>(v);
+        d_row_start[i] = d_inv_row_offsets[v];
+        d_scan[i] = d_inv_row_offsets[v];
+    }
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _MARK_PATHS>
 struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
     typedef ProblemBase<_VertexId, _SizeT, _Value, false> Base;
@@ -62,6 +86,10 @@ struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
         VertexId *d_preds = nullptr;                // MARK_PATHS: extract target
         int *d_visit_lookup = nullptr;              // de-duplication tag per vertex
         float delta = 0.0f;                         // bucket width (0 = one bucket per distance value)
+        // pull iterations (dense levels): weights of the IN-edges in inverse-CSR order, and per vertex the best candidate the
+        // reducing advance found -- a distance, or with MARK_PATHS the packed (distance << 32 | in-neighbour)
+        const unsigned *d_inv_weights = nullptr;
+        void *d_pull = nullptr;
 
         __device__ __forceinline__ unsigned Distance(VertexId v) const
         {
@@ -82,6 +110,23 @@ struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
     SizeT far_capacity = 0;
     SizeT candidate_capacity = 0;
     SizeT src_row[2] = {0, 0};
+    // in-neighbour lists with their weights (SetInverseGraph / BuildInverse): enable pull iterations
+    const SizeT *d_inv_row_offsets = nullptr;
+    const VertexId *d_inv_column_indices = nullptr;
+    SizeT *d_own_inv_row_offsets = nullptr;
+    VertexId *d_own_inv_column_indices = nullptr;
+    unsigned *d_own_inv_weights = nullptr;
+    util::Frontier<VertexId, SizeT> inv_frontier;  // every vertex that has in-edges, with the degree prefix of the in-lists
+    SizeT inv_frontier_len = 0;
+    SizeT inv_frontier_edges = 0;
+    // a level relaxes by PULL when its frontier has more than this many out-edges (-1: 3/4 of the edges; 0: never).  A pull
+    // sweeps every in-edge once, without atomics; a push pays a memory-side atomicMin (~27 G/s) per edge that looks improvable.
+    // Measured at R-MAT scale-22 (66 M edges, 16 MiB of distances -- four times an XCD's L2): a pull level costs 0.9 ms whatever
+    // the frontier, because every in-edge gathers its neighbour's distance as a 64-byte sector from beyond L2 (4.2 GB per
+    // level); a push level of 32 M frontier edges costs 0.64 ms.  So pulling pays only when the frontier holds nearly all edges.
+    long long pull_min_edges = -1;
+    bool HasInverse() const { return d_inv_row_offsets != nullptr && inv_frontier.v != nullptr; }
+    long long PullMinEdges() const { return pull_min_edges >= 0 ? pull_min_edges : static_cast<long long>(this->edges) / 4 * 3 + 1; }
 
     ~SSSPProblem() override
     {
@@ -92,7 +137,9 @@ struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
                 if (ds->d_dist_pred) hipFree(ds->d_dist_pred);
                 if (ds->d_preds) hipFree(ds->d_preds);
                 if (ds->d_visit_lookup) hipFree(ds->d_visit_lookup);
+                if (ds->d_pull) hipFree(ds->d_pull);
                 delete ds;
+                data_slices[0] = nullptr;
             }
             delete[] data_slices;
         }
@@ -102,6 +149,12 @@ struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
         }
         if (d_candidates) hipFree(d_candidates);
         if (d_weights_owned) hipFree(d_weights_owned);
+        if (d_own_inv_row_offsets) hipFree(d_own_inv_row_offsets);
+        if (d_own_inv_column_indices) hipFree(d_own_inv_column_indices);
+        if (d_own_inv_weights) hipFree(d_own_inv_weights);
+        if (inv_frontier.v) hipFree(inv_frontier.v);
+        if (inv_frontier.row_start) hipFree(inv_frontier.row_start);
+        if (inv_frontier.scan) hipFree(inv_frontier.scan);
     }
 
     hipError_t AllocData()
@@ -215,6 +268,68 @@ struct SSSPProblem : ProblemBase<_VertexId, _SizeT, _Value, false> {
     }
 
     SizeT SourceDegree() const { return src_row[1] - src_row[0]; }
+
+    // In-neighbour lists with the weight of every in-edge, in HBM (borrowed).  Enables pull iterations.
+    hipError_t SetInverseGraph(const SizeT *d_iro, const VertexId *d_ici, const unsigned *d_iw)
+    {
+        hipError_t retval = hipSuccess;
+        GraphSlice<VertexId, SizeT, Value> *gs = this->graph_slices[0];
+        DataSlice *ds = data_slices[0];
+        hipStream_t stream = gs->stream;
+        const long long n = this->nodes;
+        d_inv_row_offsets = d_iro;
+        d_inv_column_indices = d_ici;
+        ds->d_inv_weights = d_iw;
+        if (!inv_frontier.v) {
+            const size_t cap = static_cast<size_t>(n > 0 ? n : 1) + 1;
+            GR_CHECK(hipMalloc(&inv_frontier.v, sizeof(VertexId) * cap), "SSSPProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&inv_frontier.row_start, sizeof(SizeT) * cap), "SSSPProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&inv_frontier.scan, sizeof(SizeT) * cap), "SSSPProblem hipMalloc failed");
+            inv_frontier.capacity = static_cast<SizeT>(cap);
+            GR_CHECK(hipMalloc(&ds->d_pull, (MARK_PATHS ? sizeof(unsigned long long) : sizeof(unsigned)) * cap), "SSSPProblem hipMalloc failed");
+        }
+        inv_frontier_len = 0;
+        inv_frontier_edges = 0;
+        if (n <= 0) return retval;
+        unsigned *d_flags = nullptr, *d_pos = nullptr;
+        unsigned long long *d_sums = nullptr;
+        GR_CHECK(hipMalloc(&d_flags, sizeof(unsigned) * static_cast<size_t>(n + 1)), "SSSPProblem hipMalloc failed");
+        GR_CHECK(hipMalloc(&d_pos, sizeof(unsigned) * static_cast<size_t>(n + 1)), "SSSPProblem hipMalloc failed");
+        GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * static_cast<size_t>(graphio::ScanScratchWords(n + 1))), "SSSPProblem hipMalloc failed");
+        hipLaunchKernelGGL((HasInEdgesKernel<SizeT>), dim3(1024), dim3(256), 0, stream, d_iro, n, d_flags);
+        GR_CHECK(hipGetLastError(), "HasInEdgesKernel launch failed");
+        GR_CHECK(graphio::DeviceExclusiveScan<unsigned>(d_flags, d_pos, n + 1, d_sums, stream), "SSSPProblem scan failed");
+        hipLaunchKernelGGL((InFrontierKernel<VertexId, SizeT>), dim3(1024), dim3(256), 0, stream, d_iro, d_flags, d_pos, n, inv_frontier.v,
+                           inv_frontier.row_start, inv_frontier.scan);
+        GR_CHECK(hipGetLastError(), "InFrontierKernel launch failed");
+        unsigned total = 0;
+        SizeT m_inv = 0;
+        GR_CHECK(hipMemcpyAsync(&total, d_pos + n, sizeof(unsigned), hipMemcpyDeviceToHost, stream), "SSSPProblem read failed");
+        GR_CHECK(hipMemcpyAsync(&m_inv, d_iro + n, sizeof(SizeT), hipMemcpyDeviceToHost, stream), "SSSPProblem read failed");
+        GR_CHECK(hipStreamSynchronize(stream), "SSSPProblem sync failed");
+        inv_frontier_len = static_cast<SizeT>(total);
+        inv_frontier_edges = m_inv;
+        GR_CHECK(hipFree(d_flags), "SSSPProblem hipFree failed");
+        GR_CHECK(hipFree(d_pos), "SSSPProblem hipFree failed");
+        GR_CHECK(hipFree(d_sums), "SSSPProblem hipFree failed");
+        return retval;
+    }
+    // ... or built here: the transpose of the CSR, the weights travelling with their edges
+    hipError_t BuildInverse()
+    {
+        hipError_t retval = hipSuccess;
+        GraphSlice<VertexId, SizeT, Value> *gs = this->graph_slices[0];
+        if (!d_own_inv_row_offsets) {
+            const size_t m = static_cast<size_t>(this->edges > 0 ? this->edges : 1);
+            GR_CHECK(hipMalloc(&d_own_inv_row_offsets, sizeof(SizeT) * (static_cast<size_t>(this->nodes) + 2)), "SSSPProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_own_inv_column_indices, sizeof(VertexId) * m), "SSSPProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_own_inv_weights, sizeof(unsigned) * m), "SSSPProblem hipMalloc failed");
+        }
+        GR_CHECK(graphio::DeviceTransposeCsr(this->nodes, this->edges, gs->d_row_offsets, gs->d_column_indices, d_own_inv_row_offsets,
+                                             d_own_inv_column_indices, gs->stream, data_slices[0]->d_weights, d_own_inv_weights),
+                 "SSSPProblem transpose failed");
+        return SetInverseGraph(d_own_inv_row_offsets, d_own_inv_column_indices, d_own_inv_weights);
+    }
 
     hipError_t Extract(unsigned *h_labels, VertexId *h_preds)
     {

@@ -89,7 +89,8 @@ static __global__ void InDegreeKernel(const int *d_cols, long long m, unsigned *
 
 // one wave per 64 rows of the forward graph (short rows by their lane, long rows by the wave): edge (v, u) lands in row u
 static __global__ void TransposeScatterKernel(const int *d_row_offsets, const int *d_cols, int nodes, const int *d_inv_row_offsets,
-                                              unsigned *d_cursor, int *d_inv_cols)
+                                              unsigned *d_cursor, int *d_inv_cols, const unsigned *d_vals = nullptr,
+                                              unsigned *d_inv_vals = nullptr)
 {
     const unsigned lane = util::LaneId();
     const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize;
@@ -103,7 +104,9 @@ static __global__ void TransposeScatterKernel(const int *d_row_offsets, const in
         if (!long_row)
             for (int i = b; i < e; ++i) {
                 const int u = d_cols[i];
-                d_inv_cols[d_inv_row_offsets[u] + static_cast<int>(atomicAdd(d_cursor + u, 1u))] = static_cast<int>(v);
+                const int at = d_inv_row_offsets[u] + static_cast<int>(atomicAdd(d_cursor + u, 1u));
+                d_inv_cols[at] = static_cast<int>(v);
+                if (d_inv_vals) d_inv_vals[at] = d_vals[i];
             }
         unsigned long long todo = __ballot(long_row);
         while (todo) {
@@ -112,7 +115,9 @@ static __global__ void TransposeScatterKernel(const int *d_row_offsets, const in
             const int lv = static_cast<int>(g * 64 + leader);
             for (int i = lb + static_cast<int>(lane); i < le; i += util::kWaveSize) {
                 const int u = d_cols[i];
-                d_inv_cols[d_inv_row_offsets[u] + static_cast<int>(atomicAdd(d_cursor + u, 1u))] = lv;
+                const int at = d_inv_row_offsets[u] + static_cast<int>(atomicAdd(d_cursor + u, 1u));
+                d_inv_cols[at] = lv;
+                if (d_inv_vals) d_inv_vals[at] = d_vals[i];
             }
             todo &= todo - 1;
         }
@@ -120,8 +125,9 @@ static __global__ void TransposeScatterKernel(const int *d_row_offsets, const in
 }
 
 // d_inv_row_offsets[nodes + 1], d_inv_cols[edges]: caller-owned device arrays
+// d_vals / d_inv_vals (optional): one 32-bit value per edge that travels with it (SSSP weights)
 inline hipError_t DeviceTransposeCsr(int nodes, long long edges, const int *d_row_offsets, const int *d_cols, int *d_inv_row_offsets,
-                                     int *d_inv_cols, hipStream_t stream)
+                                     int *d_inv_cols, hipStream_t stream, const unsigned *d_vals = nullptr, unsigned *d_inv_vals = nullptr)
 {
     hipError_t retval = hipSuccess;
     unsigned *d_counts = nullptr;
@@ -138,7 +144,7 @@ inline hipError_t DeviceTransposeCsr(int nodes, long long edges, const int *d_ro
     GR_CHECK(hipMemsetAsync(d_counts, 0, sizeof(unsigned) * static_cast<size_t>(words), stream), "DeviceTransposeCsr memset failed");
     if (edges > 0) {
         hipLaunchKernelGGL(TransposeScatterKernel, dim3(2048), dim3(256), 0, stream, d_row_offsets, d_cols, nodes, d_inv_row_offsets, d_counts,
-                           d_inv_cols);
+                           d_inv_cols, d_vals, d_inv_vals);
         GR_CHECK(hipGetLastError(), "TransposeScatterKernel launch failed");
     }
     GR_CHECK(hipStreamSynchronize(stream), "DeviceTransposeCsr sync failed");

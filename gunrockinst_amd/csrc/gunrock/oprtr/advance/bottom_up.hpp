@@ -123,6 +123,8 @@ struct BitmapLookup {
     const unsigned *bits;
     __device__ __forceinline__ bool operator()(VertexId u) const
     {
+        // plain (L1-cached) probe: the in-neighbours asked about first are the high-degree ones, whose frontier words stay in
+        // L1 -- an L1-bypassing (sc1) probe measured 15 % slower over the whole search (0.398 vs 0.346 ms per scale-24 search)
         return (bits[static_cast<unsigned>(u) >> 5] >> (u & 31)) & 1u;
     }
 };

@@ -36,6 +36,30 @@ struct HasApplyEdgeWave<Functor, VertexId, DataSlice,
                         std::void_t<decltype(Functor::ApplyEdgeWave(VertexId(), VertexId(), false, static_cast<DataSlice *>(nullptr),
                                                                     VertexId(), VertexId()))>> : std::true_type {};
 
+// Optional split of CondEdge for functors whose test is a returning atomic:
+//   `static T IssueEdge(s_id, d_id, problem, e_id, e_id_in)`   issues the atomic and hands back what it returned, unexamined;
+//   `static bool ResolveEdge(T, s_id, d_id, problem, e_id, e_id_in)` decides from that value.
+// The advance issues all of a thread's edges first and resolves them afterwards, so the atomics' round trips overlap; with
+// CondEdge alone every edge waits for its own atomic before the next one is issued (the test sits inside the branch that
+// guards the call).  CondEdge must stay equivalent to ResolveEdge(IssueEdge(...)): operators without the batch path call it.
+template <typename Functor, typename VertexId, typename DataSlice, typename = void>
+struct HasIssueEdge : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice>
+struct HasIssueEdge<Functor, VertexId, DataSlice,
+                    std::void_t<decltype(Functor::IssueEdge(VertexId(), VertexId(), static_cast<DataSlice *>(nullptr), VertexId(), VertexId()))>>
+    : std::true_type {};
+
+// Optional hook of a REDUCING advance: `static V ReduceValue(s_id, d_id, problem, e_id, e_id_in)` computes the value an edge
+// contributes (the reference leaves this case open: "use user-specified function to generate value to reduce",
+// edge_map_partitioned/kernel.cuh:427-429); without it the value is d_value_to_reduce[d_id] / [e_id].  Side-effect free and
+// safe for any valid (vertex, vertex, edge): it is evaluated for every slot of a tile before any result is used.
+template <typename Functor, typename VertexId, typename DataSlice, typename = void>
+struct HasReduceValue : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice>
+struct HasReduceValue<Functor, VertexId, DataSlice,
+                      std::void_t<decltype(Functor::ReduceValue(VertexId(), VertexId(), static_cast<DataSlice *>(nullptr), VertexId(), VertexId()))>>
+    : std::true_type {};
+
 }  // namespace advance
 }  // namespace oprtr
 }  // namespace gunrock

@@ -119,6 +119,9 @@ struct ReduceOps {
     {
         if constexpr (OP == PLUS || OP == NONE || OP == MINUS || OP == MODULUS) {
             atomicAdd(p, v);
+        } else if constexpr (std::is_integral<T>::value && sizeof(T) == 8 && (OP == MAXIMUM || OP == MINIMUM)) {
+            if constexpr (OP == MAXIMUM) atomicMax(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v));
+            else atomicMin(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v));
         } else if constexpr (std::is_integral<T>::value && sizeof(T) == 4 && (OP == MAXIMUM || OP == MINIMUM || OP == BIT_OR || OP == BIT_AND || OP == BIT_XOR)) {
             if constexpr (OP == MAXIMUM) atomicMax(p, v);
             else if constexpr (OP == MINIMUM) atomicMin(p, v);
@@ -368,10 +371,26 @@ __device__ __forceinline__ void ExpandTiles(
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) mine += live[k] ? 1 : 0;
         } else {
+            if constexpr (HasIssueEdge<Functor, VertexId, typename ProblemData::DataSlice>::value) {
+                // survivors pay the (atomic) claim: all of them issued, then all of them examined
+                typedef decltype(Functor::IssueEdge(src[0], dst[0], &slice, edge[0], slot0)) Token;
+                Token token[ITEMS];
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
-                live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k],
-                                                       slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+                for (int k = 0; k < ITEMS; ++k) {
+                    token[k] = Token();
+                    if (live[k]) token[k] = Functor::IssueEdge(src[k], dst[k], &slice, edge[k],
+                                                               slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+                }
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k)
+                    live[k] = live[k] && Functor::ResolveEdge(token[k], src[k], dst[k], &slice, edge[k],
+                                                              slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+            } else {
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k)  // survivors pay the (atomic) claim
+                    live[k] = live[k] && Functor::CondEdge(src[k], dst[k], &slice, edge[k],
+                                                           slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+            }
             if constexpr (HasApplyEdgeWave<Functor, VertexId, typename ProblemData::DataSlice>::value) {
 #pragma unroll
                 for (int k = 0; k < ITEMS; ++k) {  // every lane calls: the functor works across the wave
@@ -398,7 +417,12 @@ __device__ __forceinline__ void ExpandTiles(
             RValue val[ITEMS];
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {  // all value loads in flight together (rejected slots read entry 0, then take the identity)
-                const RValue got = values[live[k] ? (Reducer::R_TYPE == VERTEX ? static_cast<SizeT>(dst[k]) : edge[k]) : static_cast<SizeT>(0)];
+                RValue got;
+                if constexpr (HasReduceValue<Functor, VertexId, typename ProblemData::DataSlice>::value)
+                    got = Functor::ReduceValue(live[k] ? src[k] : static_cast<VertexId>(0), live[k] ? dst[k] : static_cast<VertexId>(0), &slice,
+                                               live[k] ? edge[k] : static_cast<SizeT>(0), 0);
+                else
+                    got = values[live[k] ? (Reducer::R_TYPE == VERTEX ? static_cast<SizeT>(dst[k]) : edge[k]) : static_cast<SizeT>(0)];
                 val[k] = live[k] ? got : Ops::Identity();
             }
 #pragma unroll
@@ -406,13 +430,10 @@ __device__ __forceinline__ void ExpandTiles(
                 const int row_first = wave_base + k * util::kWaveSize;
                 const int slot = row_first + static_cast<int>(lane);
                 const int key = slot < slots ? own[k] : -1;  // owners are non-decreasing along the slots: equal keys are one run
-                RValue v = val[k];
-#pragma unroll
-                for (int o = 1; o < util::kWaveSize; o <<= 1) {
-                    const int other_key = __shfl_up(key, o, util::kWaveSize);
-                    const RValue other = __shfl_up(v, o, util::kWaveSize);
-                    if (static_cast<int>(lane) >= o && other_key == key) v = Ops::Combine(other, v);
-                }
+                // segment heads: the key changes (dead slots, key -1, form their own segment and report nothing)
+                const int prev_key = static_cast<int>(util::DppFrom<0x138, 0xF>(static_cast<unsigned>(key) ^ 1u, static_cast<unsigned>(key)));  // wave_shr:1
+                const bool head = lane == 0 || prev_key != key;
+                const RValue v = util::WaveSegmentedScanDpp<Ops, RValue>(head, val[k]);
                 const int next_key = __shfl_down(key, 1, util::kWaveSize);
                 if (key >= 0 && (lane == util::kWaveSize - 1 || next_key != key)) {  // last slot of the run
                     const int row_begin = sh.scan[key];

@@ -78,6 +78,58 @@ __device__ __forceinline__ unsigned WaveInclusiveMaxDpp(unsigned x)
     return x;
 }
 
+// DPP move of a 32- or 64-bit value (lanes without a source get `identity`)
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T DppMove(T identity, T x)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        unsigned xi, ii;
+        __builtin_memcpy(&xi, &x, 4);
+        __builtin_memcpy(&ii, &identity, 4);
+        const unsigned r = DppFrom<CTRL, ROW_MASK>(ii, xi);
+        T out;
+        __builtin_memcpy(&out, &r, 4);
+        return out;
+    } else {
+        unsigned long long xi, ii;
+        __builtin_memcpy(&xi, &x, 8);
+        __builtin_memcpy(&ii, &identity, 8);
+        const unsigned lo = DppFrom<CTRL, ROW_MASK>(static_cast<unsigned>(ii), static_cast<unsigned>(xi));
+        const unsigned hi = DppFrom<CTRL, ROW_MASK>(static_cast<unsigned>(ii >> 32), static_cast<unsigned>(xi >> 32));
+        const unsigned long long r = (static_cast<unsigned long long>(hi) << 32) | lo;
+        T out;
+        __builtin_memcpy(&out, &r, 8);
+        return out;
+    }
+}
+
+// Inclusive SEGMENTED scan across the wave on the DPP path: `head` marks the first lane of a segment; lane i ends up with
+// Combine over its segment's lanes up to i.  The pair operator (f_a, v_a) + (f_b, v_b) = (f_a | f_b, f_b ? v_b : Combine(v_a, v_b))
+// is associative, so the usual scan network (row_shr 1, 2, 4, 8; row_bcast 15, 31) applies.  Six steps of three or four VALU
+// instructions; the shuffle form (two ds_bpermute per step, each a ~100-cycle LDS-pipe round trip) dominated the reducing advance.
+template <typename Ops, typename T>
+__device__ __forceinline__ T WaveSegmentedScanDpp(bool head, T v)
+{
+    unsigned f = head ? 1u : 0u;
+    const T id = Ops::Identity();
+#define GRX_SEG_STEP(CTRL, MASK)                                   \
+    {                                                              \
+        const unsigned fo = DppFrom<CTRL, MASK>(0u, f);            \
+        const T vo = DppMove<CTRL, MASK, T>(id, v);                \
+        v = f ? v : Ops::Combine(vo, v);                           \
+        f |= fo;                                                   \
+    }
+    GRX_SEG_STEP(0x111, 0xF)
+    GRX_SEG_STEP(0x112, 0xF)
+    GRX_SEG_STEP(0x114, 0xF)
+    GRX_SEG_STEP(0x118, 0xF)
+    GRX_SEG_STEP(0x142, 0xA)
+    GRX_SEG_STEP(0x143, 0xC)
+#undef GRX_SEG_STEP
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T WaveSum(T x)
 {

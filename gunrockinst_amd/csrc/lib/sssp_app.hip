@@ -27,6 +27,8 @@ struct SsspRunner {
     virtual ~SsspRunner() {}
     virtual hipError_t Init(Csr<int, int, int> &g, int delta_factor) = 0;
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci, const unsigned *d_w, float delta) = 0;
+    virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, const unsigned *d_iw, long long pull_min_edges) = 0;
+    virtual long long PullLevels() = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, float *ms) = 0;
     virtual void Stats(long long &vertices, long long &edges, long long &iters, long long &launches, double &kernel_ms) = 0;
@@ -57,6 +59,14 @@ struct SsspRunnerT : SsspRunner {
     {
         return problem.InitFromDevice(nodes, edges, d_ro, d_ci, d_w, delta);
     }
+    hipError_t SetInverse(const int *d_iro, const int *d_ici, const unsigned *d_iw, long long pull_min_edges) override
+    {
+        if (!problem.data_slices) return hipErrorNotInitialized;
+        problem.pull_min_edges = pull_min_edges;
+        if (d_iro && d_ici && d_iw) return problem.SetInverseGraph(d_iro, d_ici, d_iw);
+        return problem.BuildInverse();
+    }
+    long long PullLevels() override { return enactor.pull_levels; }
     hipError_t Reset(int src, double queue_sizing) override { return problem.Reset(src, enactor.GetFrontierType(), queue_sizing); }
     hipError_t Enact(int src, int max_grid_size, float *ms) override
     {
@@ -130,6 +140,20 @@ int grx_sssp_init_device(grx_sssp *p, int nodes, int edges, int *d_row_offsets, 
 {
     if (!p || !d_row_offsets || !d_edge_weights || nodes < 0 || edges < 0) return -1;
     return static_cast<int>(p->runner->InitDevice(nodes, edges, d_row_offsets, d_col_indices, d_edge_weights, delta));
+}
+
+int grx_sssp_set_inverse_graph(grx_sssp *p, const int *d_inv_row_offsets, const int *d_inv_col_indices, const unsigned *d_inv_weights,
+                               long long pull_min_edges)
+{
+    if (!p) return -1;
+    return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, d_inv_weights, pull_min_edges));
+}
+
+int grx_sssp_pull_levels(grx_sssp *p, long long *levels)
+{
+    if (!p || !levels) return -1;
+    *levels = p->runner->PullLevels();
+    return 0;
 }
 
 int grx_sssp_reset(grx_sssp *p, int src, double queue_sizing) { return p ? static_cast<int>(p->runner->Reset(src, queue_sizing)) : -1; }

@@ -174,6 +174,15 @@ int grx_sssp_init(grx_sssp *p, int nodes, int edges, const int *row_offsets, con
 /* CSR + weights already in HBM (borrowed); `delta` is the bucket width to use (0 = one bucket per distance) */
 int grx_sssp_init_device(grx_sssp *p, int nodes, int edges, int *d_row_offsets, int *d_col_indices,
                          const unsigned *d_edge_weights, float delta);
+/* Enable PULL relaxation of dense levels: a level whose frontier has more than `pull_min_edges` out-edges (-1: 3/4 of the
+ * edges, 0: never) takes, for every vertex, the minimum over its IN-edges of (neighbour's distance + weight) with the reducing
+ * advance -- no atomicMin per edge -- instead of pushing along the frontier's out-edges (sssp_functor.cuh:54-64).  Needs the
+ * in-neighbour lists WITH the weight of every in-edge, in HBM (borrowed); pass NULLs to have the weighted transpose built on
+ * the device.  Distances do not depend on it.  Call after init. */
+int grx_sssp_set_inverse_graph(grx_sssp *p, const int *d_inv_row_offsets, const int *d_inv_col_indices, const unsigned *d_inv_weights,
+                               long long pull_min_edges);
+/* levels of the last Enact that were relaxed by pulling */
+int grx_sssp_pull_levels(grx_sssp *p, long long *levels);
 /* SSSPProblem::Reset(src, frontier_type, queue_sizing) (reference sssp_problem.cuh:299-377) */
 int grx_sssp_reset(grx_sssp *p, int src, double queue_sizing);
 /* SSSPEnactor::Enact(context, problem, src, queue_sizing, max_grid_size) (reference sssp_enactor.cuh:485-563) */

@@ -121,3 +121,32 @@ def test_instrumented_and_rerun():
     st = p.stats()
     assert st["kernel_launches"] > 0 and 0 < st["kernel_ms"] <= ms and st["delta"] > 0
     p.close()
+
+
+@pytest.mark.parametrize("mark_pred", [False, True])
+@pytest.mark.parametrize("pull_min_edges", [1, -1, 0])
+def test_pull_relaxation_levels(mark_pred, pull_min_edges):
+    # dense levels relaxed by PULLING over the weighted in-neighbour lists (reducing advance, MINIMUM): distances must equal the
+    # oracle's Dijkstra bit for bit, predecessors must be tight parents; pull_min_edges 1 = every level with more than one edge
+    rng = np.random.default_rng(7)
+    for scale, und in [(12, True), (15, True), (14, False)]:
+        g = o.rmat_seeded(scale, 8 << scale, undirected=und)
+        w = rng.integers(1, 65, g.edges, dtype=np.uint32)
+        deg = np.diff(g.row_offsets)
+        for src in [int(o.highest_degree_node(g)[0]), int(np.nonzero(deg > 0)[0][-1])]:
+            p = ga.SsspProblem(mark_pred).init(g.nodes, g.row_offsets, g.col_indices, w)
+            p.set_inverse_graph(pull_min_edges=pull_min_edges)      # weighted transpose built on the device
+            p.reset(src)
+            p.enact(src)
+            dist, preds = p.extract()
+            ref, _ = o.sssp(g, src, w)
+            assert np.array_equal(dist, ref)
+            if mark_pred:
+                assert o.check_sssp_preds(g, src, dist, preds, w) == 0
+            if pull_min_edges == 1 and deg[src] > 1:
+                assert p.pull_levels() > 0
+            if pull_min_edges == 0:
+                assert p.pull_levels() == 0
+            if pull_min_edges == -1:                                # default rule: only a frontier holding 3/4 of the edges pulls
+                assert p.pull_levels() == 0
+            p.close()

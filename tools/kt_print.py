@@ -4,7 +4,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 anchor = sys.argv[2] if len(sys.argv) > 2 else 'ResetKernel'
-idx = max(i for i, nm in enumerate(names) if anchor in nm)
+hits = [i for i, nm in enumerate(names) if anchor in nm]
+idx = max(hits) if hits else max(0, len(rows) - 80)
 t0 = int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
     nm = r['Kernel_Name']

@@ -15,8 +15,10 @@ delta = (int(float(w.double().mean())) * 32.0 / max(float(int(deg.double().mean(
 src = devgraph.largest_degree_source(ro)[0]
 for inst in (False, True):
     p = ga.SsspProblem(False, inst).init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+    if os.environ.get("GUNROCK_SSSP_PULL") == "1":
+        p.set_inverse_graph(pull_min_edges=int(os.environ.get("GUNROCK_SSSP_PULL_MIN", "-1")))
     for rep in range(reps):
         p.reset(src)
         ms = p.enact(src)
-    print("instrument", inst, "delta", delta, "enact ms", ms, p.stats())
+    print("instrument", inst, "delta", delta, "enact ms", ms, p.stats(), "pull levels", p.pull_levels())
     p.close()
