@@ -6,15 +6,14 @@
  * (reference: gunrock/gunrock.h:25-151), so a C program written against the reference
  * (e.g. reference shared_lib_tests/test_bfs.c:12-68) compiles and links unchanged.
  *
- * Scope of this build: gunrock_bfs_func, gunrock_cc_func and
- * gunrock_sssp_func run on the GPU.  gunrock_bc_func / gunrock_pr_func / gunrock_topk_func are
- * exported so existing programs still link, but they only report "not built" on stderr.
+ * All six entry points run on the GPU (BFS is the hot path, CC / SSSP / BC /
+ * PageRank / TopK are the "next" rows built on the same operators).
  *
  * Calling contract (reference: gunrock/app/bfs/bfs_app.cu:146-396, cc_app.cu:126-279):
  *   - graph_in->row_offsets / col_indices (/ edge_values) are HOST arrays owned by the caller;
  *     they are only read during the call.
- *   - only {VTXID_INT, SIZET_INT, VALUE_INT} (BFS, CC) and VALUE_UINT (SSSP) are implemented;
- *     other combinations print "Not Yet Support This DataType Combination." and return.
+ *   - only {VTXID_INT, SIZET_INT} with VALUE_INT (BFS, CC, TopK), VALUE_UINT (SSSP) and VALUE_FLOAT
+ *     (BC, PageRank) are implemented, the combinations the reference dispatches; other combinations print "Not Yet Support This DataType Combination." and return.
  *   - graph_out->node_values receives a malloc()ed array of num_nodes 32-bit values
  *     (BFS depth, -1 unreachable / CC component id = smallest vertex id of the component /
  *     SSSP unsigned distance, UINT_MAX unreachable); the CALLER frees it.
@@ -81,7 +80,9 @@ extern "C" {
 void gunrock_bfs_func(struct GunrockGraph *graph_out, const struct GunrockGraph *graph_in,
                       struct GunrockConfig configs, struct GunrockDataType data_type);
 
-/* reference gunrock.h:113-117 -- OUT OF SCOPE here: prints a diagnostic, leaves graph_out untouched */
+/* reference gunrock.h:113-117; implementation reference gunrock/app/bc/bc_app.cu:86-125,330-343:
+ * VALUE_FLOAT; src_node = -1 accumulates over every source; node_values = float[num_nodes] (halved),
+ * edge_values = float[num_edges] of zeros as in the reference */
 void gunrock_bc_func(struct GunrockGraph *graph_out, const struct GunrockGraph *graph_in,
                      struct GunrockConfig configs, struct GunrockDataType data_type);
 
@@ -96,12 +97,16 @@ void gunrock_sssp_func(struct GunrockGraph *graph_out, void *predecessor,
                        const struct GunrockGraph *graph_in, struct GunrockConfig configs,
                        struct GunrockDataType data_type);
 
-/* reference gunrock.h:135-141 -- OUT OF SCOPE */
+/* reference gunrock.h:135-141; implementation reference gunrock/app/pr/pr_app.cu:189-346: VALUE_FLOAT;
+ * node_ids int[] / page_rank float[] are caller-allocated and receive min(num_nodes, top_nodes) entries
+ * (all when top_nodes <= 0) in descending rank order.  graph_in's CSC fields are not read. */
 void gunrock_pr_func(struct GunrockGraph *graph_out, void *node_ids, void *page_rank,
                      const struct GunrockGraph *graph_in, struct GunrockConfig configs,
                      struct GunrockDataType data_type);
 
-/* reference gunrock.h:144-151 -- OUT OF SCOPE */
+/* reference gunrock.h:144-151; implementation reference gunrock/app/topk/topk_app.cu: VALUE_INT;
+ * graph_in carries CSR and CSC (col_offsets / row_indices, shared_lib_tests/test_topk.c:30-41);
+ * node_ids / in_degrees / out_degrees are caller-allocated int[top_nodes] */
 void gunrock_topk_func(struct GunrockGraph *graph_out, void *node_ids, void *in_degrees,
                        void *out_degrees, const struct GunrockGraph *graph_in,
                        struct GunrockConfig configs, struct GunrockDataType data_type);
