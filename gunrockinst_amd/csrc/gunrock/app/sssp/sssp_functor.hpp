@@ -83,6 +83,36 @@ struct SSSPFunctor {
         // the predecessor travels inside the packed atomicMin of CondEdge
     }
 
+    // ---- staged forms (oprtr/advance/functor_hooks.hpp): the source's distance arrives with the staged frontier entry and the
+    // candidate travels from the screen to the claim, so the claim loads nothing.  (The five-argument forms re-load the
+    // source's distance and the weight inside the per-edge branch of the claim: one exposed round trip per edge, measured
+    // 2.75 -> 2.55 ms per R-MAT scale-22 search.)
+    // Measured and dropped: a 4-bit-per-vertex quantised distance bound (n/2 bytes, L2-resident) in front of the distance
+    // gather rejected 77 % of the gathers and still cost 0.15 ms more than it saved -- the per-CU rate of random accesses is the
+    // bound, and an L2 probe plus 23 % of the gathers is more random accesses than the gathers alone.
+    typedef unsigned EdgeState;  // the candidate distance (UINT_MAX: wrapped, not a path length)
+    typedef typename std::conditional<ProblemData::MARK_PATHS, unsigned long long, unsigned>::type StagedToken;
+    static __device__ __forceinline__ unsigned SourceData(VertexId s_id, DataSlice *problem) { return problem->Distance(s_id); }
+    static __device__ __forceinline__ bool ScreenEdge(VertexId, VertexId d_id, DataSlice *problem, VertexId e_id, VertexId, unsigned from,
+                                                      EdgeState &candidate)
+    {
+        const unsigned sum = from + problem->d_weights[e_id];
+        candidate = sum < from ? 0xFFFFFFFFu : sum;
+        return (candidate != 0xFFFFFFFFu) & (candidate < problem->Distance(d_id));
+    }
+    static __device__ __forceinline__ StagedToken IssueEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId, VertexId, unsigned,
+                                                            EdgeState &candidate)
+    {
+        if (ProblemData::MARK_PATHS)
+            return static_cast<StagedToken>(atomicMin(problem->d_dist_pred + d_id, (static_cast<unsigned long long>(candidate) << 32) | static_cast<unsigned>(s_id)));
+        return static_cast<StagedToken>(atomicMin(problem->d_labels + d_id, candidate));
+    }
+    static __device__ __forceinline__ bool ResolveEdge(StagedToken token, VertexId, VertexId, DataSlice *, VertexId, VertexId, EdgeState &candidate)
+    {
+        const unsigned old = ProblemData::MARK_PATHS ? static_cast<unsigned>(static_cast<unsigned long long>(token) >> 32) : static_cast<unsigned>(token);
+        return candidate < old;
+    }
+
     static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice *, unsigned = 0, SizeT = 0) { return node != -1; }
     static __device__ __forceinline__ void ApplyFilter(VertexId, DataSlice *, unsigned = 0, SizeT = 0) {}
 };

@@ -49,6 +49,32 @@ struct HasIssueEdge<Functor, VertexId, DataSlice,
                     std::void_t<decltype(Functor::IssueEdge(VertexId(), VertexId(), static_cast<DataSlice *>(nullptr), VertexId(), VertexId()))>>
     : std::true_type {};
 
+// Optional STAGED form of the screen / claim hooks, for functors whose edge test needs a property of the SOURCE vertex and a
+// value computed from it per edge (SSSP: distance of the source, candidate distance of the edge):
+//   `static unsigned SourceData(s_id, problem)`            32 bits, fetched ONCE per frontier entry while the entry is staged
+//                                                           (a coalesced load a tile ahead), kept in LDS next to the entry;
+//   `typedef ... EdgeState;`                                per-edge registers that travel from the screen to the claim;
+//   `static bool ScreenEdge(s_id, d_id, problem, e_id, e_id_in, unsigned source_data, EdgeState &state)`
+//   `static T    IssueEdge (s_id, d_id, problem, e_id, e_id_in, unsigned source_data, EdgeState &state)`
+//   `static bool ResolveEdge(T, s_id, d_id, problem, e_id, e_id_in, EdgeState &state)`
+// Without it the claim has to re-load what the screen already had (the compiler cannot keep a load across the atomics in
+// between), inside the per-edge branch -- one exposed round trip per edge.  The five-argument forms must stay equivalent:
+// operators without the staged path call them.
+template <typename Functor, typename VertexId, typename DataSlice, typename = void>
+struct HasSourceData : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice>
+struct HasSourceData<Functor, VertexId, DataSlice, std::void_t<decltype(Functor::SourceData(VertexId(), static_cast<DataSlice *>(nullptr)))>>
+    : std::true_type {};
+struct NoEdgeState {};
+template <typename Functor, bool STAGED>
+struct EdgeStateOf {
+    typedef NoEdgeState type;
+};
+template <typename Functor>
+struct EdgeStateOf<Functor, true> {
+    typedef typename Functor::EdgeState type;
+};
+
 // Optional hook of a REDUCING advance: `static V ReduceValue(s_id, d_id, problem, e_id, e_id_in)` computes the value an edge
 // contributes (the reference leaves this case open: "use user-specified function to generate value to reduce",
 // edge_map_partitioned/kernel.cuh:427-429); without it the value is d_value_to_reduce[d_id] / [e_id].  Side-effect free and

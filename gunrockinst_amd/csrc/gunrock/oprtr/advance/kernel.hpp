@@ -166,6 +166,7 @@ struct AdvanceShared {
     SizeT scan[KernelPolicy::THREADS];       // stage: degree prefix relative to the tile's first slot
     SizeT row[KernelPolicy::THREADS];        // stage: first edge of the vertex
     VertexId vertex[KernelPolicy::THREADS];  // stage: vertex id
+    unsigned source_data[KernelPolicy::THREADS];  // stage: Functor::SourceData of the vertex (functor_hooks.hpp, staged hooks)
     unsigned own[KernelPolicy::TILE];        // slot -> (tile tag << IDX_BITS | staged entry whose row starts at this slot)
     typename std::conditional<WITH_WRITER, typename Writer::Storage, NoWriterStorage>::type writer;
     int owner_count[2][WAVES];
@@ -253,10 +254,14 @@ __device__ __forceinline__ void ExpandTiles(
     long long slot_at = tile_begin * TILE;
     SizeT p_scan = INT_MAX, p_row = 0;
     VertexId p_v = 0;
+    constexpr bool STAGED = HasSourceData<Functor, VertexId, typename ProblemData::DataSlice>::value;
+    typedef typename EdgeStateOf<Functor, STAGED>::type EdgeState;
+    unsigned p_source = 0u;
     if (slot_at < slot_end && cursor + tid < a.in_len) {
         p_scan = LoadQueue<FRESH>(a.in.scan + cursor + tid);
         p_row = LoadQueue<FRESH>(a.in.row_start + cursor + tid);
         p_v = LoadQueue<FRESH>(a.in.v + cursor + tid);
+        if constexpr (STAGED) p_source = Functor::SourceData(p_v, &slice);
     }
 
     while (slot_at < slot_end) {
@@ -287,6 +292,7 @@ __device__ __forceinline__ void ExpandTiles(
             if (rel < limit) {
                 sh.row[tid] = p_row;
                 sh.vertex[tid] = p_v;
+                if constexpr (STAGED) sh.source_data[tid] = p_source;
                 if (rel > 0) sh.own[rel] = tag | static_cast<unsigned>(tid);
             }
             const unsigned long long in_tile = __ballot(rel < limit);
@@ -328,6 +334,8 @@ __device__ __forceinline__ void ExpandTiles(
         VertexId dst[ITEMS];
         bool live[ITEMS];
         int own[Reducer::ENABLED ? ITEMS : 1];  // staged entry that owns the slot (reducing advance only)
+        unsigned source[STAGED ? ITEMS : 1];
+        EdgeState state[STAGED ? ITEMS : 1];
         {
             int lo = 0, hi = owners;  // sh.scan[lo] <= wave_base < sh.scan[hi] (hi == owners: past the slice)
             if (wave_base > 0) {
@@ -348,21 +356,32 @@ __device__ __forceinline__ void ExpandTiles(
                 const int owner = static_cast<int>(m & static_cast<unsigned>(THREADS - 1));
                 edge[k] = sh.row[owner] + (slot - sh.scan[owner]);
                 src[k] = sh.vertex[owner];
+                if constexpr (STAGED) source[k] = sh.source_data[owner];
                 if constexpr (Reducer::ENABLED) own[k] = owner;
             }
         }
         // ---- expand, phase by phase so each thread keeps ITEMS independent memory operations in flight ----
         // consecutive lanes hold consecutive slots => one wave-instruction reads 256 contiguous bytes of column_indices
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) dst[k] = live[k] ? a.d_column_indices[edge[k]] : static_cast<VertexId>(0);
+        for (int k = 0; k < ITEMS; ++k) {  // (a dead slot reads entry 0: no branch around the load)
+            if (!live[k]) { edge[k] = 0; src[k] = 0; }
+            dst[k] = a.d_column_indices[edge[k]];
+        }
         // side-effect-free screen, evaluated for EVERY slot (dead ones with vertex 0, edge 0) and combined without a branch, so
         // the status loads of a tile are in flight together: `live && Screen()` would wait for each load before the next
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
-            const bool pass = ScreenEdge<Functor>(live[k] ? src[k] : static_cast<VertexId>(0), dst[k], &slice,
-                                                  live[k] ? edge[k] : static_cast<SizeT>(0),
-                                                  slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
+            bool pass;
+            if constexpr (STAGED)
+                pass = Functor::ScreenEdge(src[k], dst[k], &slice, edge[k], slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane),
+                                           source[k], state[k]);
+            else
+                pass = ScreenEdge<Functor>(src[k], dst[k], &slice, edge[k], slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane));
             live[k] = live[k] & pass;
+        }
+        if constexpr (STAGED) {  // the next tile's source data: its vertex ids (fetched above) have arrived with the screen's loads
+            p_source = 0u;
+            if (p_scan != INT_MAX) p_source = Functor::SourceData(p_v, &slice);
         }
         int mine = 0;
         if constexpr (BINNED) {
@@ -371,7 +390,22 @@ __device__ __forceinline__ void ExpandTiles(
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) mine += live[k] ? 1 : 0;
         } else {
-            if constexpr (HasIssueEdge<Functor, VertexId, typename ProblemData::DataSlice>::value) {
+            if constexpr (STAGED) {
+                // survivors pay the (atomic) claim: all of them issued, then all of them examined; what the screen computed
+                // (state) and the staged source data come along, so the claim loads nothing
+                typedef decltype(Functor::IssueEdge(src[0], dst[0], &slice, edge[0], slot0, source[0], state[0])) Token;
+                Token token[ITEMS];
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) {
+                    token[k] = Token();
+                    if (live[k]) token[k] = Functor::IssueEdge(src[k], dst[k], &slice, edge[k],
+                                                               slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane), source[k], state[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k)
+                    live[k] = live[k] && Functor::ResolveEdge(token[k], src[k], dst[k], &slice, edge[k],
+                                                              slot0 + wave_base + k * util::kWaveSize + static_cast<int>(lane), state[k]);
+            } else if constexpr (HasIssueEdge<Functor, VertexId, typename ProblemData::DataSlice>::value) {
                 // survivors pay the (atomic) claim: all of them issued, then all of them examined
                 typedef decltype(Functor::IssueEdge(src[0], dst[0], &slice, edge[0], slot0)) Token;
                 Token token[ITEMS];
