@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6772)
     ap.add_argument("--cpu-baseline-runs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--primitive", choices=["bfs", "cc", "sssp", "bc"], default="bfs",
+    ap.add_argument("--primitive", choices=["bfs", "cc", "sssp", "bc", "pr"], default="bfs",
                     help="bfs = the headline metric (default); cc / sssp = BASELINE.json configs 4 / 3 on one GPU")
     ap.add_argument("--delta-factor", type=int, default=16)
     ap.add_argument("--skip-topdown-leg", action="store_true",
@@ -94,6 +94,8 @@ def main():
         result = bench_cc(args, torch, ga, devgraph, local_rank)
     elif args.primitive == "sssp":
         result = bench_sssp(args, torch, ga, devgraph, local_rank)
+    elif args.primitive == "pr":
+        result = bench_pr(args, torch, ga, devgraph, local_rank)
     elif args.primitive == "bc":
         result = bench_bc(args, torch, ga, devgraph, local_rank)
     else:
@@ -419,6 +421,63 @@ def bench_bc(args, torch, ga, devgraph, device_index):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": "advance::LoadBalancedKernel<Forward/BackwardFunctor>",
                          "alg_bytes": balg, "note": "whole Reset + Enact device time of a source (grx_bc_run)"},
+            "cpu_baseline": cpu}
+
+
+def bench_pr(args, torch, ga, devgraph, device_index):
+    """PageRank (the reducing advance's first user): a step = Reset + Enact of a fixed number of iterations
+    (threshold 0, so none stops early), R-MAT as for the other primitives; the graph is symmetric, so its CSR is its own
+    in-neighbour table.  Parity: against the oracle's restatement of the reference schedule, which is UNPINNED."""
+    import numpy as np
+    n = 1 << args.scale
+    ro, ci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+    m = int(ci.shape[0])
+    iters = 20
+    p = ga.PrProblem(device=device_index).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+    p.set_inverse_graph()
+    steps = max(1, min(args.steps, 10))
+    for _ in range(min(args.warmup, 2)):
+        p.reset(-1, 0.85, 0.0); p.enact(iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enact_ms = 0.0
+    for _ in range(steps):
+        p.reset(-1, 0.85, 0.0)
+        enact_ms += p.enact(iters)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    st = p.stats()
+    done = max(st["iterations"], 1)
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        from oracle import gr_oracle as o
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        g = o.Csr(n, h_ro, h_ci)
+        t0 = time.perf_counter()
+        ref, _, ref_iters = o.pagerank(g, -1, 0.85, 0.0, iters)
+        cpu_s = time.perf_counter() - t0
+        ids, ranks = p.extract()
+        by_vertex = np.zeros(n, dtype=np.float64)
+        by_vertex[ids] = ranks
+        parity = bool(np.allclose(by_vertex, ref, rtol=1e-4, atol=1e-6)) and ref_iters == done
+        cpu = {"value": round(m * ref_iters / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+               "sample": "%d iterations of the oracle's PageRank restatement (doubles, parity unpinned) on the same graph, %.1f s" % (ref_iters, cpu_s)}
+    p.close()
+    # per iteration: 4 B per in-edge (column index) + 4 B gathered contribution per in-edge + ~16 B per vertex (rank in/out, contribution, degree)
+    balg = steps * done * (8.0 * m + 16.0 * n)
+    achieved = balg / (enact_ms * 1e-3) / 1e9
+    return {"metric": "PageRank R-MAT scale-%d: MTEPS = edges x iterations / Enact time" % args.scale,
+            "value": round(m * done * steps / (enact_ms * 1e3), 2), "unit": "MTEPS", "n_gpus": 1, "steps": steps,
+            "warmup": min(args.warmup, 2), "ms_per_step": round(wall * 1e3 / steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PageRank delta 0.85, %d iterations (threshold 0), R-MAT scale-%d: n=%d, m=%d" % (done, args.scale, n, m)},
+            "enact_ms_per_step": round(enact_ms / steps, 4), "ms_per_iteration": round(enact_ms / steps / done, 4),
+            "parity_vs_oracle": parity, "parity_note": "oracle = restatement of the reference schedule, PARITY UNPINNED",
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                         "traffic": None, "kernel": "advance::ReduceKernel<PRFunctor, PLUS>",
+                         "alg_bytes_per_iteration": 8.0 * m + 16.0 * n,
+                         "note": "the contribution gather costs a 64-byte sector per edge once the table outgrows L2 (DESIGN.md 3.6): "
+                                 "physical traffic is ~8x the algorithmic 4 B"},
             "cpu_baseline": cpu}
 
 

@@ -9,11 +9,11 @@ from .capi import (  # noqa: F401
     GunrockConfig, GunrockDataType, GunrockGraph, LIB_PATH, lib, build_library,
     VTXID_INT, SIZET_INT, VALUE_INT, VALUE_UINT, VALUE_FLOAT, SRC_MANUALLY, SRC_RANDOMIZE, SRC_LARGEST_DEGREE,
     HostGraph, BfsProblem, CcProblem, SsspProblem, BcProblem, PrProblem, gunrock_bfs, gunrock_cc, gunrock_sssp, gunrock_bc,
-    gunrock_pr, gunrock_topk, version,
+    gunrock_pr, gunrock_topk, version, filter_queue,
 )
 
 __all__ = [
     "GunrockConfig", "GunrockDataType", "GunrockGraph", "LIB_PATH", "lib", "build_library",
     "HostGraph", "BfsProblem", "CcProblem", "SsspProblem", "BcProblem", "gunrock_bfs", "gunrock_cc", "gunrock_sssp",
-    "gunrock_bc", "PrProblem", "gunrock_pr", "gunrock_topk", "version",
+    "gunrock_bc", "PrProblem", "gunrock_pr", "gunrock_topk", "version", "filter_queue",
 ]

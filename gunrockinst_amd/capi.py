@@ -123,6 +123,8 @@ _SIGNATURES = {
     "grx_sssp_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
     "grx_sssp_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
     "grx_sssp_pull_levels": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    "grx_filter_queue": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_longlong), C.c_int]),
     "grx_sssp_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "grx_sssp_enact": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "grx_sssp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
@@ -655,6 +657,32 @@ class BcProblem:
             self.close()
         except Exception:
             pass
+
+
+def filter_queue(ids, row_offsets=None, capacity=None, max_grid_size=0):
+    """oprtr::filter::Kernel with the BFS functor over a queue of vertex ids (-1 = culled entry), on the GPU.
+    row_offsets given: returns (v, row_start, scan, edges) -- a complete vertex frontier, zero-degree vertices dropped;
+    else (v,).  Output order is unspecified."""
+    import numpy as np
+    import torch
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    n = int(ids.shape[0])
+    cap = int(capacity if capacity is not None else max(n, 1))
+    d_in = torch.from_numpy(ids).cuda() if n else torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_v = torch.empty(max(cap, 1), dtype=torch.int32, device="cuda")
+    out_len, out_edges = C.c_int(), C.c_longlong()
+    if row_offsets is None:
+        _check(lib().grx_filter_queue(n, C.c_void_p(d_in.data_ptr()), None, cap, C.c_void_p(d_v.data_ptr()), None, None, C.byref(out_len),
+                                      C.byref(out_edges), int(max_grid_size)), "filter::Kernel")
+        return (d_v[:out_len.value].cpu().numpy(),)
+    d_ro = torch.from_numpy(np.ascontiguousarray(row_offsets, dtype=np.int32)).cuda()
+    d_rs = torch.empty_like(d_v)
+    d_sc = torch.empty_like(d_v)
+    _check(lib().grx_filter_queue(n, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_ro.data_ptr()), cap, C.c_void_p(d_v.data_ptr()),
+                                  C.c_void_p(d_rs.data_ptr()), C.c_void_p(d_sc.data_ptr()), C.byref(out_len), C.byref(out_edges),
+                                  int(max_grid_size)), "filter::Kernel")
+    k = out_len.value
+    return d_v[:k].cpu().numpy(), d_rs[:k].cpu().numpy(), d_sc[:k].cpu().numpy(), int(out_edges.value)
 
 
 class SsspProblem:

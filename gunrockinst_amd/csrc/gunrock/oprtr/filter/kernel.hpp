@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <gunrock/oprtr/frontier_writer.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
@@ -25,6 +27,18 @@
 namespace gunrock {
 namespace oprtr {
 namespace filter {
+
+// Optional split of CondFilter for functors whose test is a returning atomic (same idea as the advance's IssueEdge /
+// ResolveEdge, oprtr/advance/functor_hooks.hpp): all elements of a thread are issued before any result is examined.
+//   `static bool ScreenFilter(node, problem, value, nid)`   side-effect free, evaluated for every element (node may be any valid id)
+//   `static T    IssueFilter(node, problem, value, nid)`     the atomic, result handed back unexamined
+//   `static bool ResolveFilter(T, node, problem, value, nid)`
+// CondFilter must stay equivalent to Screen && Resolve(Issue).
+template <typename Functor, typename VertexId, typename DataSlice, typename Value, typename SizeT, typename = void>
+struct HasIssueFilter : std::false_type {};
+template <typename Functor, typename VertexId, typename DataSlice, typename Value, typename SizeT>
+struct HasIssueFilter<Functor, VertexId, DataSlice, Value, SizeT,
+                      std::void_t<decltype(Functor::IssueFilter(VertexId(), static_cast<DataSlice *>(nullptr), Value(), SizeT()))>> : std::true_type {};
 
 template <int _THREADS, int _ITEMS_PER_THREAD, int _MIN_BLOCKS_PER_CU>
 struct KernelPolicy {
@@ -83,12 +97,33 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void Kernel(
             if (idx[k] < a.num_elements) node[k] = a.d_in ? a.d_in[idx[k]] : static_cast<VertexId>(idx[k]);
         }
         int mine = 0;
+        if constexpr (HasIssueFilter<Functor, VertexId, typename ProblemData::DataSlice, Value, SizeT>::value) {
+            typedef decltype(Functor::IssueFilter(node[0], &slice, Value(0), idx[0])) Token;
+            Token token[ITEMS];
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            keep[k] = node[k] != -1 && Functor::CondFilter(node[k], &slice, Value(0), idx[k]);
-            if (keep[k]) {
-                Functor::ApplyFilter(node[k], &slice, Value(0), idx[k]);
-                ++mine;
+            for (int k = 0; k < ITEMS; ++k)  // branch-free screens: their loads are in flight together
+                keep[k] = (node[k] != -1) & Functor::ScreenFilter(node[k] != -1 ? node[k] : static_cast<VertexId>(0), &slice, Value(0), idx[k]);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                token[k] = Token();
+                if (keep[k]) token[k] = Functor::IssueFilter(node[k], &slice, Value(0), idx[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                keep[k] = keep[k] && Functor::ResolveFilter(token[k], node[k], &slice, Value(0), idx[k]);
+                if (keep[k]) {
+                    Functor::ApplyFilter(node[k], &slice, Value(0), idx[k]);
+                    ++mine;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                keep[k] = node[k] != -1 && Functor::CondFilter(node[k], &slice, Value(0), idx[k]);
+                if (keep[k]) {
+                    Functor::ApplyFilter(node[k], &slice, Value(0), idx[k]);
+                    ++mine;
+                }
             }
         }
         int pos = Writer::Reserve(s_writer, mine);

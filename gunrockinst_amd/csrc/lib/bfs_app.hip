@@ -14,6 +14,7 @@
 #include <gunrock/app/bfs/bfs_enactor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
 #include <gunrock/graphio/symmetry.hpp>
+#include <gunrock/oprtr/filter/kernel.hpp>
 #include <gunrock/csr.hpp>
 #include <gunrock/graphio/utils.hpp>
 #include <gunrock/util/context.hpp>
@@ -311,6 +312,55 @@ int grx_bfs_device_results(grx_bfs *p, int **d_labels, int **d_preds)
 {
     if (!p) return -1;
     p->runner->DeviceResults(d_labels, d_preds);
+    return 0;
+}
+
+// The compacting filter operator on its own (reference filter::Kernel with the BFS functor, filter/kernel.cuh:211-383: CondFilter
+// = "is a valid vertex id", bfs_functor.cuh:100-105): `n` queue entries in HBM, -1 = culled.  d_row_offsets != NULL: the output
+// is a complete vertex frontier (id, first edge, exclusive degree prefix; vertices without out-edges are dropped);
+// NULL: ids only.  *out_len / *out_edges: entries written and the sum of their degrees.  Output order is not specified.
+int grx_filter_queue(int n, const int *d_in, const int *d_row_offsets, int capacity, int *d_out_v, int *d_out_row_start, int *d_out_scan,
+                     int *out_len, long long *out_edges, int max_grid_size)
+{
+    typedef BFSProblem<int, int, int, false, false, false> Problem;
+    typedef BFSFunctor<int, int, int, Problem> Functor;
+    typedef oprtr::filter::KernelPolicy<256, 4, 8> Policy;
+    if (n < 0 || !d_out_v || !out_len || (d_row_offsets && (!d_out_row_start || !d_out_scan))) return -1;
+    hipError_t retval = hipSuccess;
+    unsigned long long *d_tail = nullptr;
+    int *d_overflow = nullptr;
+    GR_CHECK(hipMalloc(&d_tail, sizeof(unsigned long long)), "grx_filter_queue hipMalloc failed");
+    GR_CHECK(hipMalloc(&d_overflow, sizeof(int)), "grx_filter_queue hipMalloc failed");
+    GR_CHECK(hipMemset(d_tail, 0, sizeof(unsigned long long)), "grx_filter_queue memset failed");
+    GR_CHECK(hipMemset(d_overflow, 0, sizeof(int)), "grx_filter_queue memset failed");
+    GR_CHECK(hipDeviceSynchronize(), "grx_filter_queue sync failed");
+    oprtr::filter::FilterArgs<int, int> f;
+    f.d_in = d_in;
+    f.num_elements = n;
+    f.out.v = d_out_v;
+    f.out.row_start = d_out_row_start;
+    f.out.scan = d_out_scan;
+    f.out.capacity = capacity;
+    f.d_tail_out = d_tail;
+    f.d_tail_clear = nullptr;
+    f.d_overflow = d_overflow;
+    f.d_row_offsets = d_row_offsets;
+    Problem::DataSlice slice{};
+    const int grid = max_grid_size > 0 ? max_grid_size : 2048;
+    if (n > 0) {
+        if (d_row_offsets) retval = oprtr::filter::LaunchKernel<Policy, Problem, Functor, true>(f, slice, grid, 0);
+        else retval = oprtr::filter::LaunchKernel<Policy, Problem, Functor, false>(f, slice, grid, 0);
+    }
+    unsigned long long tail = 0;
+    int overflow = 0;
+    if (!retval) retval = util::GRError(hipMemcpy(&tail, d_tail, sizeof(tail), hipMemcpyDeviceToHost), "grx_filter_queue read failed", __FILE__, __LINE__);
+    if (!retval) retval = util::GRError(hipMemcpy(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost), "grx_filter_queue read failed", __FILE__, __LINE__);
+    hipFree(d_tail);
+    hipFree(d_overflow);
+    if (retval) return static_cast<int>(retval);
+    if (overflow) return static_cast<int>(util::GRError(hipErrorInvalidConfiguration, "Frontier queue overflow. Please increase queue-sizing factor.", __FILE__, __LINE__));
+    *out_len = static_cast<int>(util::TailCount(tail));
+    if (out_edges) *out_edges = static_cast<long long>(util::TailEdges(tail));
     return 0;
 }
 

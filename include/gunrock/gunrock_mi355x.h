@@ -134,6 +134,14 @@ int grx_bfs_extract(grx_bfs *p, int *h_labels, int *h_preds);
 /* device result arrays (valid until destroy / next init) */
 int grx_bfs_device_results(grx_bfs *p, int **d_labels, int **d_preds);
 void grx_bfs_destroy(grx_bfs *p);
+/* The compacting filter operator by itself: reference filter::Kernel (gunrock/oprtr/filter/kernel.cuh:211-383) with the BFS
+ * functor, whose CondFilter keeps valid vertex ids (bfs_functor.cuh:100-105).  d_in[n] in HBM, -1 = culled entry.
+ * d_row_offsets != NULL: the output is a complete vertex frontier for the load-balanced advance -- id, first edge and the
+ * exclusive prefix of the degrees in OUTPUT order; vertices without out-edges are dropped -- else ids only (row_start / scan
+ * unused).  out_len entries were written (order unspecified), *out_edges = sum of their degrees.  Returns a HIP error code
+ * ("Frontier queue overflow" when capacity is too small, filter/cta.cuh:526-529). */
+int grx_filter_queue(int n, const int *d_in, const int *d_row_offsets, int capacity, int *d_out_v, int *d_out_row_start, int *d_out_scan,
+                     int *out_len, long long *out_edges, int max_grid_size);
 
 /* DisplayStats' counters (reference tests/bfs/test_bfs.cu:184-196): visited vertices and the sum of their
  * out-degrees -- the numerator of MTEPS = edges_visited / (elapsed_ms * 1000) */
@@ -251,7 +259,7 @@ typedef int (*grx_all_gather_fn)(void *ctx, const void *d_send, void *d_recv, si
 typedef int (*grx_all_to_all_v_fn)(void *ctx, const void *d_send, const size_t *send_counts, const size_t *send_offsets,
                                    void *d_recv, const size_t *recv_counts, const size_t *recv_offsets);
 int grx_pbfs_set_transport(grx_pbfs *p, void *ctx, grx_all_gather_fn all_gather, grx_all_to_all_v_fn all_to_all_v);
-/* mark_pred: exchange (id, parent) pairs on top-down levels; alpha: direction rule factor (<= 0 keeps 10) */
+/* mark_pred: exchange (id, parent) pairs on top-down levels; alpha: direction rule factor (<= 0 keeps the default, 30) */
 int grx_pbfs_set_options(grx_pbfs *p, int mark_pred, float alpha);
 /* Reset + the whole search from `src` (a GLOBAL vertex id, the same on every rank); levels = BSP levels executed;
  * elapsed_ms = device time of this rank from the reset to the last level (HIP events on the engine's stream) */
