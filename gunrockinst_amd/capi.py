@@ -64,6 +64,7 @@ _SIGNATURES = {
     "gunrock_topk_func": (None, [C.POINTER(GunrockGraph), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(GunrockGraph), GunrockConfig, GunrockDataType]),
     "grx_graph_from_market": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "grx_graph_from_market_cached": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "grx_graph_rmat_libc": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [C.POINTER(C.c_void_p)]),
     "grx_graph_rmat_seeded": (C.c_int, [C.c_int, C.c_longlong, C.c_uint64, C.c_int] + [C.c_double] * 4 +
                               [C.POINTER(C.c_void_p)]),
@@ -208,8 +209,17 @@ class HostGraph:
         self.edges = L.grx_graph_edges(self._h)
 
     @classmethod
-    def from_market(cls, path, undirected=False, reversed_=False):
+    def from_market(cls, path, undirected=False, reversed_=False, cache=False):
+        """cache=True: the reference's CSR cache rule with a binary, stamped cache file next to the input; the instance's
+        `cache_hit` tells whether the graph came from it."""
         h = C.c_void_p()
+        if cache:
+            hit = C.c_int()
+            _check(lib().grx_graph_from_market_cached(os.fsencode(path), int(undirected), int(reversed_), C.byref(hit), C.byref(h)),
+                   "BuildMarketGraphCached(%s)" % path)
+            g = cls(h.value)
+            g.cache_hit = bool(hit.value)
+            return g
         _check(lib().grx_graph_from_market(os.fsencode(path), int(undirected), int(reversed_), C.byref(h)),
                "BuildMarketGraph(%s)" % path)
         return cls(h.value)

@@ -36,6 +36,20 @@ int grx_graph_from_market(const char *path, int undirected, int reversed, grx_gr
     return 0;
 }
 
+int grx_graph_from_market_cached(const char *path, int undirected, int reversed, int *cache_hit, grx_graph **out)
+{
+    if (!path || !out) return -1;
+    grx_graph *g = new (std::nothrow) grx_graph();
+    if (!g) return -2;
+    if (gunrock::graphio::BuildMarketGraphCached<true>(const_cast<char *>(path), g->csr, undirected != 0, reversed != 0, cache_hit)) {
+        delete g;
+        return -3;
+    }
+    g->has_values = true;
+    *out = g;
+    return 0;
+}
+
 int grx_graph_rmat_libc(int nodes, int edges, int undirected, double a, double b, double c, double d, grx_graph **out)
 {
     if (!out) return -1;

@@ -29,6 +29,11 @@ typedef struct grx_graph grx_graph;
 
 /* graphio::BuildMarketGraph<true>(file, csr, undirected, reversed)  (reference graphio/market.cuh:296-339) */
 int grx_graph_from_market(const char *path, int undirected, int reversed, grx_graph **out);
+/* The same with the reference's CSR cache rule (market.cuh:296-339, csr.cuh:140-232: "<dir>/.<name>_{undirected,reversed,
+ * nonreversed}_csr" written after the first parse and preferred afterwards), made safe: the cache is BINARY ("....bin"), and
+ * is used only when it was written for a source file of exactly this size and modification time; *cache_hit (may be NULL)
+ * tells which way the graph came.  An unwritable directory is not an error. */
+int grx_graph_from_market_cached(const char *path, int undirected, int reversed, int *cache_hit, grx_graph **out);
 /* graphio::BuildRmatGraph<true>(nodes, edges, csr, undirected, a,b,c,d) on libc rand() (reference graphio/rmat.cuh:27-91) */
 int grx_graph_rmat_libc(int nodes, int edges, int undirected, double a, double b, double c, double d, grx_graph **out);
 /* seeded counter-based R-MAT: 2^scale vertices, `pairs` generated edges (mirrored when undirected) */

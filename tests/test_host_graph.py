@@ -101,3 +101,83 @@ def test_empty_and_edgeless_graphs():
     assert g.edges == 0 and g.row_offsets.tolist() == [0] * 6
     g = ga.HostGraph.from_coo(3, np.array([1, 2], np.int32), np.array([1, 2], np.int32))   # only self loops
     assert g.edges == 0 and g.highest_degree_node() == (0, 0)
+
+
+def _both(path, **kw):
+    """(library graph | None, oracle graph | None): None = that side refused the file."""
+    try:
+        g = ga.HostGraph.from_market(path, **kw)
+    except RuntimeError:
+        g = None
+    try:
+        r = o.build_market(path, kw.get("undirected", False), kw.get("reversed_", False))
+    except Exception:
+        r = None
+    return g, r
+
+
+def test_market_line_cutting_matches_the_fscanf_loop(tmp_path):
+    # The library scans the file from memory by hand; the oracle keeps the reference's fscanf("%1023[^\n]\n") + sscanf pair
+    # (market.cuh:81-83,139-148).  Both must cut and read these inputs alike: CRLF, tabs, signs, trailing text after the
+    # numbers, comment lines of 1023 / 1024 / 3000 characters (a longer line continues as the NEXT line), white space before
+    # the first line, a newline as the very first byte (ends the parse), a value that overflows 64 bits.
+    body = "3 1 4\n1 2 7\n2 3\n"
+    cases = {
+        "crlf": "%%MatrixMarket\r\n3 3 3\r\n" + body.replace("\n", "\r\n"),
+        "tabs": "%c\n3\t3\t3\n3\t1\t4\n1 \t 2 \t+7 trailing words\n  2   3   \n\n\n",
+        "signs": "3 3 3\n3 1 -4\n1 2 +7\n2 3 0009\n",
+        "long1023": "%" * 1023 + "\n3 3 3\n" + body,
+        "long1024": "%" * 1024 + "\n3 3 3\n" + body,
+        "long3000": "%" * 3000 + "\n3 3 3\n" + body,
+        "long_split_becomes_data": "%" + "x" * 1022 + "3 3 3\n" + body,        # the 1024th character starts a new "line"
+        "leading_space": "   \n3 3 3\n" + body,
+        "newline_first": "\n3 3 3\n" + body,
+        "overflow": "3 3 3\n3 1 99999999999999999999999\n1 2 7\n2 3\n",
+        "float_first_column": "3 3 3\n3.5 1 4\n1 2 7\n2 3\n",
+        "no_trailing_newline": "3 3 3\n3 1 4\n1 2 7\n2 3",
+        "too_many": "3 3 2\n3 1 4\n1 2 7\n2 3\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".mtx")
+        p.write_bytes(text.encode())
+        for kw in ({}, {"undirected": True}, {"reversed_": True}):
+            g, r = _both(str(p), **kw)
+            assert (g is None) == (r is None), (name, kw)
+            if g is not None:
+                _same(g, r)
+
+
+def test_market_binary_cache(tmp_path):
+    # reference rule: "<dir>/.<name>_{undirected,reversed,nonreversed}_csr" after the first parse, preferred afterwards
+    # (market.cuh:296-339) -- here binary and stamped with the source's size and mtime, so a changed input is never shadowed
+    p = tmp_path / "g.mtx"
+    p.write_text("4 4 4\n2 1 3\n3 1 5\n4 3 2\n1 4 8\n")
+    first = ga.HostGraph.from_market(str(p), cache=True)
+    assert not first.cache_hit and (tmp_path / ".g.mtx_nonreversed_csr.bin").exists()
+    again = ga.HostGraph.from_market(str(p), cache=True)
+    assert again.cache_hit
+    _same(again, first)
+    _same(again, o.build_market(str(p)))
+    und = ga.HostGraph.from_market(str(p), undirected=True, cache=True)      # another mode: its own cache file
+    assert not und.cache_hit and (tmp_path / ".g.mtx_undirected_csr.bin").exists()
+    rev = ga.HostGraph.from_market(str(p), reversed_=True, cache=True)
+    assert not rev.cache_hit and (tmp_path / ".g.mtx_reversed_csr.bin").exists()
+    _same(ga.HostGraph.from_market(str(p), undirected=True, cache=True), o.build_market(str(p), True))
+    # the input changes (same name): the stale cache must lose
+    p.write_text("4 4 3\n2 1 3\n3 1 5\n4 3 2\n")
+    os.utime(str(p), ns=(1, 1))
+    changed = ga.HostGraph.from_market(str(p), cache=True)
+    assert not changed.cache_hit and changed.edges == 3
+    assert ga.HostGraph.from_market(str(p), cache=True).cache_hit
+    # a truncated or foreign cache file is not a hit either
+    c = tmp_path / ".g.mtx_nonreversed_csr.bin"
+    c.write_bytes(c.read_bytes()[:-4])
+    g = ga.HostGraph.from_market(str(p), cache=True)
+    assert not g.cache_hit and g.edges == 3
+    c.write_bytes(b"not a cache")
+    assert not ga.HostGraph.from_market(str(p), cache=True).cache_hit
+    # the plain loader never looks at caches
+    p2 = tmp_path / "h.mtx"
+    p2.write_text("3 3 1\n2 1\n")
+    ga.HostGraph.from_market(str(p2))
+    assert not (tmp_path / ".h.mtx_nonreversed_csr.bin").exists()
