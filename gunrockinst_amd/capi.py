@@ -97,6 +97,7 @@ _SIGNATURES = {
     "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
+    "grx_bfs_set_twc_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_binned_min_edges": (C.c_int, [C.c_void_p, C.c_longlong]),
     "grx_bfs_set_cooperative_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_head_pass": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -342,6 +343,10 @@ class BfsProblem:
 
     def set_persistent_limit(self, edge_limit):
         _check(lib().grx_bfs_set_persistent_limit(self._h, int(edge_limit)), "grx_bfs_set_persistent_limit")
+        return self
+
+    def set_twc_limit(self, edge_limit):
+        _check(lib().grx_bfs_set_twc_limit(self._h, int(edge_limit)), "grx_bfs_set_twc_limit")
         return self
 
     def reset(self, src, queue_sizing=1.0):

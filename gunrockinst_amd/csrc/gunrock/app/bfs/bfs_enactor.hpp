@@ -20,6 +20,7 @@
 #include <gunrock/app/enactor_base.hpp>
 #include <gunrock/oprtr/advance/bottom_up.hpp>
 #include <gunrock/oprtr/advance/kernel.hpp>
+#include <gunrock/oprtr/advance/twc.hpp>
 #include <gunrock/util/context.hpp>
 
 namespace gunrock {
@@ -100,7 +101,7 @@ class BFSEnactor : public EnactorBase {
     template <typename BFSProblem, typename BfsFunctor>
     hipError_t RunTail(BFSProblem *problem, long long &iteration, int &selector, unsigned &queue_length, unsigned &queue_edges,
                        long long &unexplored_edges, hipStream_t stream, bool persistent = false, double switch_factor = 0.0,
-                       bool frontier_size_unknown = false)
+                       bool frontier_size_unknown = false, bool twc = false)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
@@ -120,7 +121,11 @@ class BFSEnactor : public EnactorBase {
         t.d_row_offsets = gs->d_row_offsets;
         t.d_column_indices = gs->d_column_indices;
         t.d_overflow = work_progress.d_overflow;
-        if (persistent) {
+        if (twc) {
+            // thread / wave / workgroup tiers in one resident workgroup, frontier in LDS (oprtr/advance/twc.hpp)
+            t.edge_limit = problem->twc_edge_limit;
+            if ((retval = oprtr::advance::LaunchTwcLevels<BFSProblem, BfsFunctor>(t, *problem->data_slices[0], stream))) return retval;
+        } else if (persistent) {
             oprtr::advance::PersistentArgs<VertexId, SizeT> p;
             p.t = t;
             // Grid barrier cost grows with the number of workgroups (2048^2 grid graph, ~16 K edges per level: 16 us per
@@ -385,6 +390,20 @@ class BFSEnactor : public EnactorBase {
                     break;
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 2);
                 continue;  // the loop re-examines the frontier the tail kernel left (empty, or too large for it)
+            } else if (persistent_levels && !bottom_up && problem->twc_edge_limit > 0 &&
+                       queue_length <= static_cast<unsigned>(oprtr::advance::kTwcCapacity) &&
+                       queue_edges <= static_cast<unsigned>(problem->twc_edge_limit) &&
+                       !(dobfs && static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges))) {
+                // low-degree graph (or traversal_mode 1), small frontier: the TWC tiers keep the frontier in LDS and run levels
+                // until one outgrows it -- a road-like graph's whole search
+                const long long before = iteration;
+                snapshot_valid = false;
+                if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
+                                                              unexplored_edges, stream, false, 0.0, false, true)))
+                    break;
+                if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 8);
+                if (iteration != before) continue;
+                if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;  // no level ran: fall through to the grid kernels
             } else if (!bottom_up && queue_edges <= static_cast<unsigned>(problem->tail_edge_limit)) {
                 // small top-down frontier: run as many levels as stay small inside one launch
                 const long long before = iteration;

@@ -137,6 +137,9 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     float alpha = 10.0f;  // top-down -> bottom-up when frontier_edges * alpha > unexplored_edges (measured optimum 8..14 on R-MAT)
     float beta = 4000.0f; // bottom-up -> top-down when frontier_vertices * beta < nodes (measured at scale-24: 24..200 equal, 1000..4000 a little better;
                           // the reference's vertex rule, dobfs_enactor.cuh:569, with a later switch: sweeps of a nearly finished search are cheap)
+    // traversal_mode 1 / low-degree graphs: a frontier of at most kTwcCapacity vertices and this many edges runs in the TWC
+    // workgroup (oprtr/advance/twc.hpp); 0 = never
+    int twc_edge_limit = 8192;
     float lite_factor = 12.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
     // direction-optimizing: a level that would run count-only or bottom-up and has between min and max frontier edges starts
     // with a heads-only bottom-up pass.  -1 = automatic: edges/30 .. edges/7.8 (measured on R-MAT scale-24: below, the plain

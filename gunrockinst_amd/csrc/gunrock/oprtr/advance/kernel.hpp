@@ -813,6 +813,8 @@ struct PersistentArgs {
                                // barriers: the single-workgroup tail kernel inside this launch) until a level outgrows it
     long long unexplored_edges;  // direction-optimizing: leave when edges * switch_factor > unexplored (0 factor = never)
     double switch_factor;
+    SizeT leave_below = 0;     // > 0: after at least one level, leave when a level has fewer edge slots than this (the host has
+                               // a cheaper kernel for small levels: the TWC workgroup, twc.hpp)
 };
 
 template <typename KernelPolicy, typename ProblemData, typename Functor>
@@ -849,6 +851,7 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
         // every workgroup evaluates the same values => the same decision
         if (len == 0 || edges > t.edge_limit || done >= t.max_levels) break;
         if (p.switch_factor > 0 && static_cast<double>(edges) * p.switch_factor > static_cast<double>(unexplored)) break;
+        if (p.leave_below > 0 && done > 0 && edges < p.leave_below) break;
         if (!solo && edges <= p.solo_edges) {
             if (blockIdx.x != 0) return;  // (the others are past the last barrier they take part in)
             solo = true;

@@ -35,6 +35,7 @@ struct BfsRunner {
     virtual hipError_t AutoInverse(bool &enabled) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual void SetPersistentLimit(int limit) = 0;
+    virtual void SetTwcLimit(int limit) = 0;
     virtual void SetCooperativeLaunch(bool on) = 0;
     virtual void SetBinnedMinEdges(long long min_edges) = 0;
     virtual void SetHeadPass(int min_edges, int max_edges) = 0;
@@ -95,6 +96,7 @@ struct BfsRunnerT : BfsRunner {
         return retval;
     }
     void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
+    void SetTwcLimit(int limit) override { problem.twc_edge_limit = limit; }
     void SetCooperativeLaunch(bool on) override { problem.cooperative_launch = on; }
     void SetBinnedMinEdges(long long min_edges) override { problem.binned_min_edges = min_edges; }
     void SetHeadPass(int min_edges, int max_edges) override
@@ -259,6 +261,13 @@ int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit)
 {
     if (!p || !p->runner || edge_limit < 0) return 1;
     p->runner->SetPersistentLimit(edge_limit);
+    return 0;
+}
+
+int grx_bfs_set_twc_limit(grx_bfs *p, int edge_limit)
+{
+    if (!p || !p->runner || edge_limit < 0) return 1;
+    p->runner->SetTwcLimit(edge_limit);
     return 0;
 }
 

@@ -104,6 +104,10 @@ int grx_bfs_set_tuning(grx_bfs *p, float alpha, float beta, float lite_factor, i
  * kernel (one resident workgroup per CU, grid barrier between levels; 0 disables).  This is what the reference's
  * traversal_mode 1 (TWC advance for low-degree, high-diameter graphs, tests/bfs/test_bfs.cu:563-566) is for. */
 int grx_bfs_set_persistent_limit(grx_bfs *p, int edge_limit);
+/* traversal_mode 1 / graphs of average degree <= 8: a top-down frontier of at most 4096 vertices and `edge_limit` edges (default
+ * 8192; 0 = never) runs in the TWC workgroup -- thread / wave / workgroup tiers by neighbour-list length (reference
+ * edge_map_forward/cta.cuh:224-545), frontier kept in LDS, level after level inside one launch -- until a level outgrows it. */
+int grx_bfs_set_twc_limit(grx_bfs *p, int edge_limit);
 /* Launch that kernel with hipLaunchCooperativeKernel (the runtime then refuses a grid that exceeds the occupancy query at
  * launch time; costs ~15-19 us of host time per launch).  Off by default: a plain launch of the same grid has the same
  * residency, and the grid barrier's timeout word reports a lost co-residency at run time either way. */

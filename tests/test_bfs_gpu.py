@@ -240,6 +240,39 @@ def test_enactor_schedules_do_not_change_results(lite_factor, tail_limit):
             p.close()
 
 
+@pytest.mark.parametrize("twc_limit", [64, 5000, 65536, 1 << 22])
+def test_twc_levels_kernel_parity(twc_limit):
+    # thread / wave / workgroup tiers in one resident workgroup with the frontier in LDS (oprtr/advance/twc.hpp; the reference's
+    # TWC advance, edge_map_forward/cta.cuh:224-545, picked by traversal_mode 1 / average degree <= 8, test_bfs.cu:563-566).
+    # Grids: whole searches inside the kernel.  R-MAT: hub rows go through the wave and workgroup tiers, a level with hundreds
+    # of medium rows overflows the deferred lists, the hub's level outgrows the LDS queue (spill + hand-over through the
+    # frontier writer), small limits make it hand back early; labels / parents must equal the oracle's in every case.
+    from gunrockinst_amd import devgraph
+    graphs = []
+    for side, frac in [(200, 0.0), (256, 0.02)]:
+        ro, ci = devgraph.grid_csr_device(side, frac)
+        h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+        graphs.append((o.Csr(side * side, h_ro, h_ci), [0, side * side // 2 + side // 2]))
+    for scale in (12, 16, 18):
+        g = o.rmat_seeded(scale, 8 << scale)
+        deg = np.diff(g.row_offsets)
+        graphs.append((g, [o.highest_degree_node(g)[0], int(np.nonzero(deg == 1)[0][0]), int(np.nonzero(deg == 0)[0][0])]))
+    star = 20000                                              # one list far beyond the wave tier, leaves of degree 1
+    hg = ga.HostGraph.from_coo(star, np.zeros(star - 1, np.int32), np.arange(1, star, dtype=np.int32))
+    ro_s, ci_s = np.array(hg.row_offsets), np.array(hg.col_indices)
+    graphs.append((o.Csr(star, ro_s, ci_s), [0]))
+    for g, srcs in graphs:
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_twc_limit(twc_limit)
+            for src in srcs:
+                p.reset(int(src))
+                p.enact(int(src), traversal_mode=1)
+                labels, preds = p.extract()
+                _check(g, int(src), labels, preds, p.stats())
+            p.close()
+
+
 @pytest.mark.parametrize("persistent_limit,tail_limit", [(1 << 20, 8192), (1 << 20, 0), (1 << 14, 256), (0, 8192)])
 def test_persistent_levels_kernel_parity(persistent_limit, tail_limit):
     # mid-size levels inside the persistent multi-workgroup kernel (grid barrier between levels) versus launch-per-level:
@@ -259,6 +292,7 @@ def test_persistent_levels_kernel_parity(persistent_limit, tail_limit):
             p.set_inverse_graph()
             p.set_tuning(tail_edge_limit=tail_limit)
             p.set_persistent_limit(persistent_limit)
+            p.set_twc_limit(0)                              # (mode 1 would otherwise run its small levels in the TWC workgroup)
             p.set_cooperative_launch(mark_pred)             # half of the runs through hipLaunchCooperativeKernel
             for src in srcs:
                 for mode in (0, 1, 2):
