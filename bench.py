@@ -255,7 +255,8 @@ def bench_single(args, torch, ga, devgraph, device_index):
     names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel / BottomUpSparseKernel",
              2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
              4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel",
-             7: "BinnedExpandKernel + BinnedApplyKernel + FreshToBitmapKernel + BitmapToQueueKernel (binned top-down)"}
+             7: "BinnedExpandKernel + BinnedApplyKernel + FreshToBitmapKernel + BitmapToQueueKernel (binned top-down)",
+             8: "advance::TwcLevelsKernel"}
     by_kind = {}
     kernel_ms, launches, balg = 0.0, 0, 0.0
     for k in range(min(args.steps, len(sources))):

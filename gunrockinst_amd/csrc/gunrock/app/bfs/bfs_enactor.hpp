@@ -77,15 +77,16 @@ class BFSEnactor : public EnactorBase {
     static constexpr int kTailMaxLevels = 4096;
 
     // traversal_mode: 0 = load-balanced top-down advance (reference default, bfs_enactor.cuh:581-697);
-    //                 1 = the reference's TWC choice for low-degree graphs: LB advance + persistent mid-size levels;
+    //                 1 = the reference's TWC choice for low-degree graphs: TWC workgroup for small frontiers
+    //                     (oprtr/advance/twc.hpp), persistent mid-size levels, LB advance for the rest;
     //                 2 = direction-optimizing (reference app/dobfs): needs BFSProblem::SetInverseGraph.
     template <typename BFSProblem>
     hipError_t Enact(util::DeviceContext & /*context*/, BFSProblem *problem, typename BFSProblem::VertexId src,
                      int max_grid_size = 0, int traversal_mode = 0)
     {
         // The reference's driver picks mode 1 (TWC) for graphs of average degree <= 8 (tests/bfs/test_bfs.cu:563-566): long
-        // runs of small levels.  Here that case is served by the persistent levels kernel, enabled by mode 1 or by the
-        // same average-degree rule; on scale-free graphs a mid-size level is a one-level transition and a plain launch wins.
+        // runs of small levels.  Here that case is served by the TWC workgroup and the persistent levels kernel, enabled by
+        // mode 1 or by the same average-degree rule; on scale-free graphs a mid-size level is a one-level transition and a plain launch wins.
         const bool low_degree = static_cast<long long>(problem->edges) <= 8ll * problem->nodes;
         return EnactBFS<LBAdvancePolicy, BFSProblem>(problem, src, max_grid_size,
                                                      traversal_mode == 2 && problem->direction_optimizing,
