@@ -317,14 +317,23 @@ class LibraryBfs:
         self.engine, self.comm = engine, comm
         self.lib = engine.lib
         self._h = engine._h
-        if transport == "rccl":
+        if transport in ("rccl", "rccl-or-callbacks"):
+            # every rank must end up on the same transport: the outcome of each step is agreed on before the next one
             buf = C.create_string_buffer(128)
-            if comm.rank == 0:
-                HipEngine._check(self.lib.grx_rccl_unique_id(buf), "grx_rccl_unique_id")
-            box = [bytes(buf.raw)]
+            rc = self.lib.grx_rccl_unique_id(buf) if comm.rank == 0 else 0
+            box = [bytes(buf.raw), int(rc)]
             dist.broadcast_object_list(box, src=0, group=comm.group)
-            HipEngine._check(self.lib.grx_pbfs_comm_init_rccl(self._h, box[0]), "grx_pbfs_comm_init_rccl")
-        else:
+            rc = box[1]
+            if rc == 0:
+                rc = self.lib.grx_pbfs_comm_init_rccl(self._h, box[0])
+                (rc,) = comm.all_reduce_max([abs(int(rc))])
+            if rc != 0:
+                if transport == "rccl":
+                    raise RuntimeError("gunrockinst_amd: the library could not create its RCCL communicator (code %d)" % rc)
+                transport = "callbacks"  # (the same C++ loop; the exchanges go through torch.distributed)
+            else:
+                transport = "rccl"
+        if transport == "callbacks":
             self._gather_cb = _GATHER_FN(self._all_gather)
             self._a2a_cb = _A2A_FN(self._all_to_all_v)
             HipEngine._check(self.lib.grx_pbfs_set_transport(self._h, None, C.cast(self._gather_cb, C.c_void_p),
@@ -456,7 +465,7 @@ def bench(args, rank, world, local_rank):
         def search(s):
             return bfs.run(s, True, sticky_bottom_up=True)
     else:
-        bfs = LibraryBfs(eng, comm, transport="callbacks" if comm.host_staged else "rccl", mark_pred=False)
+        bfs = LibraryBfs(eng, comm, transport="callbacks" if comm.host_staged else "rccl-or-callbacks", mark_pred=False)
 
         def search(s):
             return bfs.search(s, True)[0]
@@ -510,7 +519,8 @@ def bench(args, rank, world, local_rank):
                                                "level loop in C++ inside the library; top-down levels: RCCL count all-gather + grouped send/recv of ids; from the first "
                                                "bottom-up level on one all-gather of the frontier bitmaps per level (sizes ride along)" if not python_loop
                                                else "level loop in Python over torch.distributed (protocol model)", n, m_global),
-                   "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend},
+                   "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend,
+                   "transport": "python loop" if python_loop else bfs.transport},
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_oracle": parity,
         "level_loop_profile_ms_per_step": ({k: round(v * 1e3 / max(bfs_runs, 1), 4) for k, v in sorted(bfs.profile.items())}
