@@ -128,14 +128,30 @@ struct BitmapLookup {
         return (bits[static_cast<unsigned>(u) >> 5] >> (u & 31)) & 1u;
     }
 };
+// Frontier bitmaps of `parts` ranks, one after the other (the all-gather's layout); vertex u is bit (u / parts) of rank
+// (u mod parts).  The quotient comes from a multiplication by a precomputed reciprocal: gfx950 has no integer divide, a
+// runtime-divisor u / parts is a ~35-instruction sequence, and this runs once per probed in-edge of a bottom-up sweep.
+// Exact for 0 <= u < 2^31 and parts <= 2^15 (magic = floor(2^shift / parts) + 1, shift = 32 + ceil(log2 parts):
+// u * (magic * parts - 2^shift) < 2^shift, and u * magic < 2^64).
 template <typename VertexId>
 struct StripedBitmapLookup {
     const unsigned *bits;
     unsigned parts;
     unsigned words_per_rank;
+    unsigned long long magic;
+    unsigned shift;
+    __host__ __device__ StripedBitmapLookup(const unsigned *bits_, unsigned parts_, unsigned words_per_rank_)
+        : bits(bits_), parts(parts_), words_per_rank(words_per_rank_)
+    {
+        unsigned s = 0;
+        while ((1u << s) < parts) ++s;
+        shift = 32 + s;
+        magic = (1ull << shift) / parts + 1ull;
+    }
     __device__ __forceinline__ bool operator()(VertexId u) const
     {
-        const unsigned owner = static_cast<unsigned>(u) % parts, local = static_cast<unsigned>(u) / parts;
+        const unsigned local = static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(u)) * magic) >> shift);
+        const unsigned owner = static_cast<unsigned>(u) - local * parts;
         return (bits[owner * words_per_rank + (local >> 5)] >> (local & 31)) & 1u;
     }
 };

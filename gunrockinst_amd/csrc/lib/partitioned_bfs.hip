@@ -214,25 +214,49 @@ __global__ void MailKernel(const unsigned *d_src, int count, int stride, unsigne
     if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// everything Reset has to seed, in one launch (the step-wise Reset does it with seven tiny copies and two stream syncs)
-__global__ void PbfsSeedKernel(int src, int parts, int rank, const int *d_row_offsets, int *d_labels, int *d_preds,
-                               unsigned *d_visited, unsigned *d_sent, util::Frontier<int, int> queue0, unsigned long long *d_tail0)
+// Reset of a search in ONE launch (Pbfs::Search): labels, parents, the visited bitmap and its "before the level" snapshot
+// (edgeless vertices pre-marked when d_never is given), the sender's global bitmap, the enactor's tail ring / overflow flag /
+// wide counters, and the source patched in: label 0 and queue entry on its owner, "already forwarded" everywhere.
+__global__ void PbfsResetKernel(int src, int parts, int rank, const int *d_row_offsets, int *d_labels, int *d_preds, long long n_local,
+                                unsigned *d_visited, unsigned *d_before, const unsigned *d_never, long long local_words, unsigned *d_sent,
+                                long long sent_words, util::Frontier<int, int> queue0, unsigned long long *d_tail, int tail_slots,
+                                int *d_overflow, unsigned long long *d_wide, int wide_words)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    d_sent[src >> 5] = 1u << (src & 31);  // every rank: the source is never forwarded
-    unsigned long long tail = 0ull;
-    if (src % parts == rank) {
-        const int local = src / parts;
-        const int begin = d_row_offsets[local], end = d_row_offsets[local + 1];
-        d_labels[local] = 0;
-        d_preds[local] = -1;
-        d_visited[local >> 5] |= 1u << (local & 31);  // (the word may hold preloaded never-bits)
-        queue0.v[0] = local;
-        queue0.row_start[0] = begin;
-        queue0.scan[0] = 0;
-        if (end > begin) tail = util::PackTail(1u, static_cast<unsigned>(end - begin));
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool mine = src % parts == rank;
+    const int local = src / parts;
+    for (long long i = tid; i < n_local; i += stride) {
+        const bool is_src = mine && i == local;
+        d_labels[i] = is_src ? 0 : -1;
+        d_preds[i] = is_src ? -1 : -2;
     }
-    *d_tail0 = tail;
+    for (long long w = tid; w < local_words; w += stride) {
+        const unsigned never = d_never ? d_never[w] : 0u;
+        d_before[w] = never;
+        d_visited[w] = (mine && w == (local >> 5)) ? (never | (1u << (local & 31))) : never;
+    }
+    for (long long w = tid; w < sent_words; w += stride) d_sent[w] = (w == (src >> 5)) ? (1u << (src & 31)) : 0u;
+    if (tid < wide_words) d_wide[tid] = 0ull;
+    if (tid == 0) {
+        *d_overflow = 0;
+        unsigned long long tail = 0ull;
+        if (mine) {
+            const int begin = d_row_offsets[local], end = d_row_offsets[local + 1];
+            queue0.v[0] = local;
+            queue0.row_start[0] = begin;
+            queue0.scan[0] = 0;
+            if (end > begin) tail = util::PackTail(1u, static_cast<unsigned>(end - begin));
+        }
+        for (int s = 0; s < tail_slots; ++s) d_tail[s] = s == 0 ? tail : 0ull;
+    }
+}
+
+// start of a top-down level: the two tail slots and the owner histogram (counts, cursors) back to zero -- one launch
+__global__ void PbfsArmLevelKernel(unsigned long long *d_tail, unsigned *d_small)
+{
+    if (threadIdx.x < 2) d_tail[threadIdx.x] = 0ull;
+    if (threadIdx.x < 128) d_small[threadIdx.x] = 0u;
 }
 
 // sum of the wide tail lines (the bottom-up sweep's per-workgroup find counts) -> one word, lines cleared
@@ -837,19 +861,14 @@ struct Pbfs : app::EnactorBase {
         if (src < 0 || src >= n_global) return hipErrorInvalidValue;
         GR_CHECK(hipEventRecord(ev_start, stream), "Pbfs hipEventRecord failed");
         // ---- reset + seed (the reference times Reset outside Enact; here it is inside the call and the bench says so) ----
-        util::Memset(ds.d_labels, -1, n_local, stream);
-        util::Memset(ds.d_preds, -2, n_local, stream);
-        const size_t local_mask_bytes = sizeof(unsigned) * (MaskWords(n_local) + 2);
-        if (direction_optimizing)  // (symmetric graph: edgeless vertices start out "visited", the sweeps skip them)
-            GR_CHECK(hipMemcpyAsync(ds.d_visited_mask, d_never, local_mask_bytes, hipMemcpyDeviceToDevice, stream), "Pbfs visited preload failed");
-        else
-            util::Memset(ds.d_visited_mask, 0u, MaskWords(n_local) + 2, stream);
+        // (direction-optimizing = symmetric graph: edgeless vertices start out "visited", the sweeps skip them)
         never_applied = direction_optimizing;
-        util::Memset(ds.d_sent_mask, 0u, MaskWords(n_global) + 2, stream);
-        if ((retval = work_progress.Reset(stream))) return retval;
-        hipLaunchKernelGGL(PbfsSeedKernel, dim3(1), dim3(64), 0, stream, src, parts, rank, d_row_offsets, ds.d_labels, ds.d_preds,
-                           ds.d_visited_mask, ds.d_sent_mask, queues[0], work_progress.d_tail + 0);
-        GR_CHECK(hipGetLastError(), "PbfsSeedKernel launch failed");
+        hipLaunchKernelGGL(PbfsResetKernel, dim3(cu_count * 8), dim3(256), 0, stream, src, parts, rank, d_row_offsets, ds.d_labels, ds.d_preds,
+                           static_cast<long long>(n_local), ds.d_visited_mask, d_visited_before, direction_optimizing ? d_never : nullptr,
+                           static_cast<long long>(MaskWords(n_local) + 2), ds.d_sent_mask, static_cast<long long>(MaskWords(n_global) + 2),
+                           queues[0], work_progress.d_tail, util::WorkProgress::kSlots, work_progress.d_overflow, work_progress.d_wide,
+                           util::WorkProgress::kWideLines * util::WorkProgress::kWideStride);
+        GR_CHECK(hipGetLastError(), "PbfsResetKernel launch failed");
         selector = 0; cur_mask = 0; level = 0;
         unsigned long long glen = 0, gedges = 0;
         if ((retval = GlobalTail(work_progress.d_tail + 0, glen, gedges, frontier_len, frontier_edges))) return retval;
@@ -857,10 +876,6 @@ struct Pbfs : app::EnactorBase {
         int levels = 0;
         const int wpr = MaskWords(n_local_max);  // bitmap words per rank; two trailing words carry the frontier size
         const int wpr_local = MaskWords(n_local);
-        if (direction_optimizing)
-            GR_CHECK(hipMemcpyAsync(d_visited_before, d_never, local_mask_bytes, hipMemcpyDeviceToDevice, stream), "Pbfs snapshot preload failed");
-        else
-            GR_CHECK(hipMemsetAsync(d_visited_before, 0, local_mask_bytes, stream), "Pbfs memset failed");
         long long local_found = frontier_len;  // local vertices with edges discovered so far (sizes the compacting-sweep test)
         while (glen > 0) {
             if (direction_optimizing && static_cast<double>(gedges) * alpha > static_cast<double>(unexplored)) {
@@ -902,8 +917,8 @@ struct Pbfs : app::EnactorBase {
             unexplored -= static_cast<long long>(gedges);
             GR_CHECK(hipMemcpyAsync(d_visited_before, ds.d_visited_mask, sizeof(unsigned) * (wpr_local + 2), hipMemcpyDeviceToDevice, stream),
                      "Pbfs visited snapshot failed");
-            GR_CHECK(hipMemsetAsync(work_progress.d_tail, 0, sizeof(unsigned long long) * 2, stream), "Pbfs clear tail failed");
-            GR_CHECK(hipMemsetAsync(d_small, 0, sizeof(unsigned) * 128, stream), "Pbfs clear counts failed");
+            hipLaunchKernelGGL(PbfsArmLevelKernel, dim3(1), dim3(128), 0, stream, work_progress.d_tail, d_small);
+            GR_CHECK(hipGetLastError(), "PbfsArmLevelKernel launch failed");
             if (frontier_len > 0) {
                 oprtr::advance::AdvanceArgs<int, int> args;
                 args.in = queues[selector];
