@@ -49,7 +49,7 @@ class BCEnactor : public EnactorBase {
         typedef typename BCProblem::SizeT SizeT;
         typedef typename BCProblem::Value Value;
         typedef ForwardFunctor<VertexId, SizeT, Value, BCProblem> Forward;
-        typedef BackwardFunctor<VertexId, SizeT, Value, BCProblem> Backward;
+        typedef BackwardReduceFunctor<VertexId, SizeT, Value, BCProblem> Backward;
 
         hipError_t retval = hipSuccess;
         if ((retval = EnactorBase::Setup(max_grid_size, AdvancePolicy::MIN_BLOCKS, 8))) return retval;
@@ -109,7 +109,8 @@ class BCEnactor : public EnactorBase {
         enactor_stats.iteration = iteration;
 
         // ---- backward: dependencies, deepest frontier with out-edges first (the deepest level has nothing below it) ----
-        for (long long level = static_cast<long long>(level_len.size()) - 2; level >= 0; --level) {
+        // (level 0 is the source alone, which accumulates nothing: bc_functor.cuh:205-208)
+        for (long long level = static_cast<long long>(level_len.size()) - 2; level >= 1; --level) {
             if (level_edges[level] <= 0) continue;
             ds->iteration = static_cast<VertexId>(level);
             oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
@@ -122,8 +123,11 @@ class BCEnactor : public EnactorBase {
             args.d_tail_out = nullptr;  // count-only launch, count not wanted
             args.d_tail_clear = nullptr;
             args.d_overflow = work_progress.d_overflow;
-            if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BCProblem, Backward, true, true>(args, *ds, max_grid_size, stream,
-                                                                                                        oprtr::advance::V2V)))
+            // delta[s] of this level's vertices <- sum over their edges into the level below (deltas are zero since Reset and
+            // every vertex is reduced into exactly once, so no identity fill)
+            if ((retval = oprtr::advance::LaunchReduce<AdvancePolicy, BCProblem, Backward, oprtr::advance::VERTEX, oprtr::advance::PLUS, Value,
+                                                       true>(args, *ds, static_cast<const Value *>(nullptr), ds->d_deltas, max_grid_size,
+                                                             stream, static_cast<long long>(problem->nodes), false)))
                 return retval;
         }
         // dependencies are final: fold them into the running centralities, once per vertex

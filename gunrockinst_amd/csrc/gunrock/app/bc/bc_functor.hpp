@@ -40,6 +40,33 @@ struct ForwardFunctor {
         if (old == -1 || old == new_label) atomicAdd(problem->d_sigmas + d_id, problem->d_sigmas[s_id]);
         return old == -1;  // the discovering edge enqueues d (exactly one per vertex)
     }
+    // ---- staged forms (oprtr/advance/functor_hooks.hpp): the source's path count arrives with the staged frontier entry, the
+    // atomicCAS of every surviving edge of a tile is issued before any of them is examined (CondEdge alone waits for its own CAS
+    // and then loads sigma[s] inside the per-edge branch: two exposed round trips per edge) ----
+    struct EdgeState {
+        Value sigma_s;  // path count of the source, as staged with the frontier entry
+    };
+    static __device__ __forceinline__ unsigned SourceData(VertexId s_id, DataSlice *problem)
+    {
+        static_assert(sizeof(Value) == 4, "32-bit path counts");
+        return __float_as_uint(problem->d_sigmas[s_id]);
+    }
+    static __device__ __forceinline__ bool ScreenEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId e_id, VertexId e_id_in,
+                                                      unsigned source_data, EdgeState &state)
+    {
+        state.sigma_s = __uint_as_float(source_data);
+        return ScreenEdge(s_id, d_id, problem, e_id, e_id_in);
+    }
+    static __device__ __forceinline__ VertexId IssueEdge(VertexId, VertexId d_id, DataSlice *problem, VertexId, VertexId, unsigned, EdgeState &)
+    {
+        return atomicCAS(problem->d_labels + d_id, static_cast<VertexId>(-1), static_cast<VertexId>(problem->iteration + 1));
+    }
+    static __device__ __forceinline__ bool ResolveEdge(VertexId old, VertexId, VertexId d_id, DataSlice *problem, VertexId, VertexId, EdgeState &state)
+    {
+        // discovered here, or already on this level: either way the edge lies on shortest paths (result unused: nothing waits)
+        if (old == -1 || old == problem->iteration + 1) atomicAdd(problem->d_sigmas + d_id, state.sigma_s);
+        return old == -1;
+    }
     static __device__ __forceinline__ void ApplyEdge(VertexId /*s_id*/, VertexId /*d_id*/, DataSlice * /*problem*/,
                                                      VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
@@ -51,6 +78,8 @@ struct ForwardFunctor {
     static __device__ __forceinline__ void ApplyFilter(VertexId /*node*/, DataSlice * /*problem*/, Value /*v*/ = 0, SizeT /*nid*/ = 0) {}
 };
 
+// (The reference's shape of the backward functor, kept for callers written against it; BCEnactor itself runs the backward phase
+//  with BackwardReduceFunctor below.)
 template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
 struct BackwardFunctor {
     typedef typename ProblemData::DataSlice DataSlice;
@@ -101,6 +130,30 @@ struct BackwardFunctor {
         return node != -1;
     }
     static __device__ __forceinline__ void ApplyFilter(VertexId /*node*/, DataSlice * /*problem*/, Value /*v*/ = 0, SizeT /*nid*/ = 0) {}
+};
+
+// Backward phase as a REDUCING advance (advance::LaunchReduce, PLUS, results by vertex): delta[s] = sum over the out-edges s -> d
+// with label[d] == label[s] + 1 of sigma[s] / sigma[d] * (1 + delta[d]).  The operator keeps the per-edge values in registers,
+// sums each run of a source's consecutive edge slots inside the wave and issues one store (the whole list sat in the run) or one
+// atomicAdd per run -- what BackwardFunctor::ApplyEdgeWave does by hand, but with all loads of a tile in flight together
+// (ApplyEdgeWave is called slot by slot: one exposed round trip each).
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct BackwardReduceFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) { return true; }
+    static __device__ __forceinline__ void ApplyEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) {}
+    // the value an edge s -> d contributes to delta[s] -- zero unless d lies one level below s.  Branch-free: an edge that fails the label test reads the source's own entries (hot lines) instead of
+    // the destination's, so a tile's label loads and then its sigma / delta loads are in flight together.
+    static __device__ __forceinline__ Value ReduceValue(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
+                                                        VertexId /*e_id_in*/ = 0)
+    {
+        const bool below = problem->d_labels[d_id] == problem->iteration + 1;
+        const VertexId from = below ? d_id : s_id;
+        const Value term = (static_cast<Value>(1) + problem->d_deltas[from]) / problem->d_sigmas[from];
+        return below ? problem->d_sigmas[s_id] * term : static_cast<Value>(0);
+    }
+    static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice *, Value = 0, SizeT = 0) { return node != -1; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) {}
 };
 
 }  // namespace bc

@@ -737,17 +737,22 @@ inline T HostIdentity()
 // whose every edge fails get the operator's identity.  ApplyEdge runs for the passing edges as in a plain advance; nothing is
 // enqueued.  One launch (plus the identity fill): no device-wide segmented-reduce pass over a materialised edge-value array.
 // BY_VERTEX: results indexed by vertex id; `out_len` = entries of d_reduced_value to pre-set (0 = the frontier length).
+// prefill = false: the caller guarantees that the output entries of this frontier already hold the operator's identity (BC's
+// dependency sums: zero since Reset, every vertex is reduced into once) -- the other entries of the array are left alone.
 template <typename KernelPolicy, typename ProblemData, typename Functor, REDUCE_TYPE R_TYPE, REDUCE_OP R_OP, typename Value, bool BY_VERTEX = false>
 hipError_t LaunchReduce(AdvanceArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> args,
                         const typename ProblemData::DataSlice &slice, const Value *d_value_to_reduce, Value *d_reduced_value,
-                        int max_grid_size, hipStream_t stream, long long out_len = 0)
+                        int max_grid_size, hipStream_t stream, long long out_len = 0, bool prefill = true)
 {
     static_assert(R_TYPE != EMPTY && R_OP != NONE, "a reducing advance needs a reduction");
     if (out_len <= 0) out_len = args.in_len;
     if (out_len <= 0) return hipSuccess;
-    hipLaunchKernelGGL((FillKernel<Value>), dim3(static_cast<unsigned>((out_len + 1023) / 1024 < 2048 ? (out_len + 1023) / 1024 : 2048)),
-                       dim3(256), 0, stream, d_reduced_value, HostIdentity<R_OP, Value>(), out_len);
-    hipError_t rc = util::GRError("advance::FillKernel launch failed", __FILE__, __LINE__);
+    hipError_t rc = hipSuccess;
+    if (prefill) {
+        hipLaunchKernelGGL((FillKernel<Value>), dim3(static_cast<unsigned>((out_len + 1023) / 1024 < 2048 ? (out_len + 1023) / 1024 : 2048)),
+                           dim3(256), 0, stream, d_reduced_value, HostIdentity<R_OP, Value>(), out_len);
+        rc = util::GRError("advance::FillKernel launch failed", __FILE__, __LINE__);
+    }
     if (rc || args.in_edges <= 0 || args.in_len <= 0) return rc;
     args.d_value_to_reduce = d_value_to_reduce;
     args.d_reduced_value = d_reduced_value;
