@@ -108,9 +108,10 @@ class BCEnactor : public EnactorBase {
         }
         enactor_stats.iteration = iteration;
 
-        // ---- backward: dependencies, deepest frontier with out-edges first (the deepest level has nothing below it) ----
-        // (level 0 is the source alone, which accumulates nothing: bc_functor.cuh:205-208)
-        for (long long level = static_cast<long long>(level_len.size()) - 2; level >= 1; --level) {
+        // ---- backward: dependencies, deepest recorded frontier first.  The recorded levels are the ones that have out-edges: the
+        // last one can still have children -- vertices WITHOUT out-edges (sinks of a directed graph), which the frontier writer
+        // does not enqueue -- so it takes part.  (Level 0 is the source alone, which accumulates nothing: bc_functor.cuh:205-208.)
+        for (long long level = static_cast<long long>(level_len.size()) - 1; level >= 1; --level) {
             if (level_edges[level] <= 0) continue;
             ds->iteration = static_cast<VertexId>(level);
             oprtr::advance::AdvanceArgs<VertexId, SizeT> args;

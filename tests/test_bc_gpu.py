@@ -110,3 +110,25 @@ def test_edge_cases():
         _, bc = p.extract()
         assert _close(bc, o.bc(g, src)[0])
     p.close()
+
+
+def test_directed_graphs_with_sinks():
+    # Vertices without out-edges are never enqueued, so the deepest RECORDED frontier can still have children: 0 -> 1 -> {2, 3}
+    # gives vertex 1 the pairs (0, 2) and (0, 3).  (Found by tools/fuzz_others.py: the backward phase used to skip that level.)
+    g = o.Csr(4, [0, 1, 3, 3, 3], [1, 2, 3])
+    p = ga.BcProblem().init(g.nodes, g.row_offsets, g.col_indices)
+    p.run(0)
+    _, bc = p.extract()
+    ref, _ = o.bc(g, 0)
+    assert ref.tolist() == [0.0, 1.0, 0.0, 0.0]                        # (halved like the reference's drivers)
+    assert _close(bc, ref)
+    p.close()
+    for scale, ef in [(6, 20), (10, 4), (13, 8)]:                      # directed R-MAT: many sinks on every level
+        g = o.rmat_seeded(scale, ef << scale, undirected=False)
+        deg = np.diff(g.row_offsets)
+        p = ga.BcProblem().init(g.nodes, g.row_offsets, g.col_indices)
+        for src in [int(np.argmax(deg)), 5, int(np.nonzero(deg > 0)[0][-1])]:
+            p.run(src)
+            _, bc = p.extract()
+            assert _close(bc, o.bc(g, src)[0])
+        p.close()
