@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primitive", choices=["bfs", "cc", "sssp", "bc", "pr"], default="bfs",
                     help="bfs = the headline metric (default); cc / sssp = BASELINE.json configs 4 / 3 on one GPU")
-    ap.add_argument("--delta-factor", type=int, default=16)
+    ap.add_argument("--delta-factor", type=float, default=16)
     ap.add_argument("--skip-topdown-leg", action="store_true",
                     help="omit the secondary top-down-only figure (keeps rocprof summaries to the headline configuration)")
     ap.add_argument("--alpha", type=float, default=0.0, help="direction switch tuning (0 = library default)")
