@@ -95,6 +95,7 @@ _SIGNATURES = {
     "grx_bfs_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p]),
     "grx_bfs_init_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grx_bfs_set_inverse_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "grx_bfs_auto_inverse": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "grx_bfs_set_tuning": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_twc_limit": (C.c_int, [C.c_void_p, C.c_int]),
@@ -324,6 +325,14 @@ class BfsProblem:
         _check(lib().grx_bfs_set_inverse_graph(self._h, C.c_void_p(d_inv_row_offsets), C.c_void_p(d_inv_col_indices),
                                                alpha, beta), "BFSProblem::SetInverseGraph")
         return self
+
+    def auto_inverse(self, build_if_directed=True):
+        """What gunrock_bfs_func does before its search: symmetric graph -> its own inverse; directed -> transpose built on the
+        device (owned by the handle).  Returns (enabled, built, build_ms)."""
+        on, made, ms = C.c_int(), C.c_int(), C.c_float()
+        _check(lib().grx_bfs_auto_inverse(self._h, int(bool(build_if_directed)), C.byref(on), C.byref(made), C.byref(ms)),
+               "grx_bfs_auto_inverse")
+        return bool(on.value), bool(made.value), float(ms.value)
 
     def set_tuning(self, alpha=0.0, beta=0.0, lite_factor=-1.0, tail_edge_limit=-1):
         _check(lib().grx_bfs_set_tuning(self._h, alpha, beta, lite_factor, tail_edge_limit), "grx_bfs_set_tuning")

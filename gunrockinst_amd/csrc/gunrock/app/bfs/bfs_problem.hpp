@@ -77,7 +77,9 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
             l[src & 3] = 0;
             p[src & 3] = -1;
         }
+#ifndef GRX_EXP_NO_LABELS
         labels4[k] = l;
+#endif
         if (PRED) preds4[k] = p;
     }
     for (long long i = nvec * 4 + tid; i < nodes; i += stride) {

@@ -267,6 +267,14 @@ class PREnactor : public EnactorBase {
             if (DEBUG) std::printf("iteration %lld: %u vertices moved by more than the threshold\n", enactor_stats.iteration, active);
             if (active == 0 || enactor_stats.iteration >= max_iteration) break;
         }
+        if (len == 0) {
+            // Peeling removed every vertex (any DAG): the reference's `while (done[0] < 0)` loop still runs ONE pass over its empty
+            // queue (pr_enactor.cuh:341-498) -- iteration becomes 1 and the whole-array rank_next -> rank_curr copy (:478-482)
+            // leaves every rank at 0, not at the initial 1 - delta.
+            hipLaunchKernelGGL((ZeroPeeledKernel<SizeT, Value>), dim3(sweep), dim3(256), 0, stream, ds->d_degrees, ds->d_rank_curr, n);
+            if ((retval = util::GRError("ZeroPeeledKernel launch failed", __FILE__, __LINE__))) return retval;
+            enactor_stats.iteration = 1;
+        }
 
         // ---- 3. vertices by descending rank ----
         if ((retval = problem->sorter.Reserve(n))) return retval;

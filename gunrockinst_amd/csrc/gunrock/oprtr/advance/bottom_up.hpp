@@ -93,7 +93,9 @@ __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, uns
         while (mine) {
             const int b = __builtin_ctz(mine);
             mine &= mine - 1;
+#ifndef GRX_EXP_NO_LABELS
             d_labels[v0 + b] = label;
+#endif
         }
         if (quad == 0 && in_range) {
             d_frontier_out[my_word] = d_merge ? (mask | d_merge[my_word]) : mask;  // (d_merge: this level's head-pass finds)
@@ -437,7 +439,11 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane);
                 const bool late = active && p_found >= 0;
                 if (late) {
-                    slice.d_labels[v] = new_label;
+#ifndef GRX_EXP_NO_LABELS
+    #ifndef GRX_EXP_NO_LABELS
+                slice.d_labels[v] = new_label;
+#endif
+#endif
                     if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = p_found;
                     found_count += 1;
                 }
@@ -454,7 +460,11 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 const bool found = parent[j] >= 0;
                 if (found) {
                     const VertexId v = static_cast<VertexId>((step * STEP_WORDS + j) * 64 + lane);
-                    slice.d_labels[v] = new_label;
+#ifndef GRX_EXP_NO_LABELS
+    #ifndef GRX_EXP_NO_LABELS
+                slice.d_labels[v] = new_label;
+#endif
+#endif
                     if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent[j];
                     found_count += 1;
                 }
@@ -598,7 +608,9 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
                 if (more && late >= 0) parent = late;
             }
             if (parent >= 0) {
+#ifndef GRX_EXP_NO_LABELS
                 slice.d_labels[v] = new_label;
+#endif
                 if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
                 atomicOr(&s_found[wave][2 * j + (bit >> 5)], 1u << (bit & 31));
             }

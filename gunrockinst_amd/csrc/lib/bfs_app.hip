@@ -13,6 +13,7 @@
 
 #include <gunrock/app/bfs/bfs_enactor.hpp>
 #include <gunrock/app/bfs/bfs_problem.hpp>
+#include <gunrock/graphio/device_sort.hpp>
 #include <gunrock/graphio/symmetry.hpp>
 #include <gunrock/oprtr/filter/kernel.hpp>
 #include <gunrock/csr.hpp>
@@ -32,7 +33,7 @@ struct BfsRunner {
     virtual hipError_t Init(const Csr<int, int, int> &g) = 0;
     virtual hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) = 0;
     virtual hipError_t SetInverse(const int *d_iro, const int *d_ici, float alpha, float beta) = 0;
-    virtual hipError_t AutoInverse(bool &enabled) = 0;
+    virtual hipError_t AutoInverse(bool &enabled, bool &built, float &build_ms, bool build_if_directed = true) = 0;
     virtual void SetTuning(float alpha, float beta, float lite_factor, int tail_edge_limit) = 0;
     virtual void SetPersistentLimit(int limit) = 0;
     virtual void SetTwcLimit(int limit) = 0;
@@ -64,6 +65,7 @@ struct BfsRunnerT : BfsRunner {
     {
         if (start) hipEventDestroy(start);
         if (stop) hipEventDestroy(stop);
+        FreeInverse();
     }
     hipError_t Init(const Csr<int, int, int> &g) override { return problem.Init(false, g, 1); }
     hipError_t InitDevice(int nodes, int edges, int *d_ro, int *d_ci) override
@@ -77,13 +79,17 @@ struct BfsRunnerT : BfsRunner {
         return problem.SetInverseGraph(d_iro, d_ici, alpha, beta);
     }
     // One-shot callers (gunrock_bfs_func) hand over host arrays only.  Direction-optimizing traversal needs the in-neighbour
-    // lists: the CSR itself when every edge has its mirror (checked on the device).  The CSC fields of GunrockGraph are NOT
-    // read: the reference's BFS ignores them and its own test leaves them uninitialised (shared_lib_tests/test_bfs.c:36-42),
-    // so a drop-in must not dereference them.  A directed graph stays top-down.
-    hipError_t AutoInverse(bool &enabled) override
+    // lists: the CSR itself when every edge has its mirror (checked on the device, graphio/symmetry.hpp), else its transpose,
+    // built on the device (graphio::DeviceTransposeCsr) and owned by this runner -- the reference's DOBFS takes the inverse graph
+    // from its caller (dobfs_enactor.cuh:397,569; DOBFSProblem::Init), whose driver builds it on the host from the same .mtx.
+    // The CSC fields of GunrockGraph are NOT read: the reference's BFS ignores them and its own test leaves them uninitialised
+    // (shared_lib_tests/test_bfs.c:36-42), so a drop-in must not dereference them.
+    hipError_t AutoInverse(bool &enabled, bool &built, float &build_ms, bool build_if_directed) override
     {
         hipError_t retval = hipSuccess;
         enabled = false;
+        built = false;
+        build_ms = 0.f;
         if (!problem.data_slices || problem.nodes <= 0 || problem.edges <= 0) return retval;
         GraphSlice<int, int, int> *gs = problem.graph_slices[0];
         bool symmetric = false;
@@ -92,9 +98,33 @@ struct BfsRunnerT : BfsRunner {
         if (symmetric) {
             GR_CHECK(problem.InverseIsSelf(), "BFS InverseIsSelf failed");
             enabled = true;
+            return retval;
         }
+        if (!build_if_directed) return retval;
+        GR_CHECK(hipEventRecord(start, gs->stream), "hipEventRecord failed");
+        FreeInverse();
+        GR_CHECK(hipMalloc(&d_inv_row_offsets, sizeof(int) * (static_cast<size_t>(problem.nodes) + 1)), "BFS hipMalloc inverse offsets failed");
+        GR_CHECK(hipMalloc(&d_inv_column_indices, sizeof(int) * static_cast<size_t>(problem.edges)), "BFS hipMalloc inverse columns failed");
+        GR_CHECK(graphio::DeviceTransposeCsr(problem.nodes, problem.edges, gs->d_row_offsets, gs->d_column_indices, d_inv_row_offsets,
+                                             d_inv_column_indices, gs->stream),
+                 "BFS transpose failed");
+        GR_CHECK(problem.SetInverseGraph(d_inv_row_offsets, d_inv_column_indices), "BFS SetInverseGraph failed");
+        GR_CHECK(hipEventRecord(stop, gs->stream), "hipEventRecord failed");
+        GR_CHECK(hipEventSynchronize(stop), "hipEventSynchronize failed");
+        GR_CHECK(hipEventElapsedTime(&build_ms, start, stop), "hipEventElapsedTime failed");
+        enabled = true;
+        built = true;
         return retval;
     }
+    void FreeInverse()
+    {
+        if (d_inv_row_offsets) util::GRError(hipFree(d_inv_row_offsets), "BFS hipFree inverse offsets failed", __FILE__, __LINE__);
+        if (d_inv_column_indices) util::GRError(hipFree(d_inv_column_indices), "BFS hipFree inverse columns failed", __FILE__, __LINE__);
+        d_inv_row_offsets = nullptr;
+        d_inv_column_indices = nullptr;
+    }
+    int *d_inv_row_offsets = nullptr;     // in-neighbour CSR built by AutoInverse for a directed input (owned)
+    int *d_inv_column_indices = nullptr;
     void SetPersistentLimit(int limit) override { problem.persistent_edge_limit = limit; }
     void SetTwcLimit(int limit) override { problem.twc_edge_limit = limit; }
     void SetCooperativeLaunch(bool on) override { problem.cooperative_launch = on; }
@@ -234,6 +264,18 @@ int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const in
 {
     if (!p) return -1;
     return static_cast<int>(p->runner->SetInverse(d_inv_row_offsets, d_inv_col_indices, alpha, beta));
+}
+
+int grx_bfs_auto_inverse(grx_bfs *p, int build_if_directed, int *enabled, int *built, float *build_ms)
+{
+    if (!p || !p->runner) return -1;
+    bool on = false, made = false;
+    float ms = 0.f;
+    const hipError_t rc = p->runner->AutoInverse(on, made, ms, build_if_directed != 0);
+    if (enabled) *enabled = on ? 1 : 0;
+    if (built) *built = made ? 1 : 0;
+    if (build_ms) *build_ms = ms;
+    return static_cast<int>(rc);
 }
 
 int grx_bfs_set_head_pass(grx_bfs *p, int min_edges, int max_edges)
@@ -408,12 +450,15 @@ void gunrock_bfs_func(struct GunrockGraph *graph_out, const struct GunrockGraph 
     BfsRunner *runner = MakeRunner(configs.mark_pred, configs.idempotence, false, configs.device);
     float elapsed = 0;
     hipError_t rc = runner->Init(csr);
-    // The reference's entry point always runs its top-down enactor (bfs_app.cu:196-200).  Here a graph that is its own inverse
-    // runs direction-optimizing (the reference's separate DOBFS primitive): same labels, a fraction of the edges looked at.
-    // Small graphs stay top-down: the in-neighbour tables would cost more than the search.
-    bool dobfs = false;
+    // The reference's entry point always runs its top-down enactor (bfs_app.cu:196-200).  Here the search runs direction-
+    // optimizing (the reference's separate DOBFS primitive): on the graph itself when it is its own inverse, else on the
+    // transpose built on the device -- same labels, a fraction of the edges looked at.  Like the reference's Init, the setup is
+    // outside the Enact timer; its cost is printed.  Small graphs stay top-down: the in-neighbour tables would cost more than
+    // the search.
+    bool dobfs = false, built = false;
+    float build_ms = 0.f;
     if (!rc && csr.edges >= (1 << 16))
-        rc = util::GRError(runner->AutoInverse(dobfs), "BFS inverse graph setup failed", __FILE__, __LINE__);
+        rc = util::GRError(runner->AutoInverse(dobfs, built, build_ms), "BFS inverse graph setup failed", __FILE__, __LINE__);
     if (!rc) rc = util::GRError(runner->Reset(src, queue_sizing), "BFS Problem Data Reset Failed", __FILE__, __LINE__);
     if (!rc) rc = util::GRError(runner->Enact(src, 0, dobfs ? 2 : 0, &elapsed), "BFS Problem Enact Failed", __FILE__, __LINE__);
     long long queued = 0, depth = 0, launches = 0;
@@ -421,7 +466,10 @@ void gunrock_bfs_func(struct GunrockGraph *graph_out, const struct GunrockGraph 
     runner->Stats(queued, depth, duty, launches, kernel_ms);
     if (!rc) rc = util::GRError(runner->Extract(h_labels, nullptr), "BFS Problem Data Extraction Failed", __FILE__, __LINE__);
     graph_out->node_values = h_labels;  // caller frees (bfs_app.cu:211)
-    if (!rc && dobfs) std::printf("[GPU Breadth-first search] symmetric input: direction-optimizing traversal.\n");
+    if (!rc && dobfs && !built) std::printf("[GPU Breadth-first search] symmetric input: direction-optimizing traversal.\n");
+    if (!rc && dobfs && built)
+        std::printf("[GPU Breadth-first search] directed input: direction-optimizing traversal on the device-built inverse graph (%.3f ms).\n",
+                    build_ms);
     if (!rc) DisplayStats("GPU Breadth-first search", src, h_labels, csr, elapsed, depth, queued, duty);
     delete runner;
     csr.row_offsets = nullptr;

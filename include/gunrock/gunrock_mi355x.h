@@ -94,6 +94,12 @@ int grx_bfs_init_device(grx_bfs *p, int nodes, int edges, int *d_row_offsets, in
  * keep the defaults.  Takes effect with traversal_mode = 2 in grx_bfs_enact.  Call after init. */
 int grx_bfs_set_inverse_graph(grx_bfs *p, const int *d_inv_row_offsets, const int *d_inv_col_indices,
                               float alpha, float beta);
+/* What gunrock_bfs_func does before its search: when the CSR is its own inverse (every edge mirrored; checked on the device)
+ * the graph serves as its own in-neighbour lists; otherwise, with build_if_directed != 0, the transpose is built on the device and
+ * owned by the handle (the reference's DOBFS driver builds the inverse graph on the host, tests/dobfs/test_dobfs.cu; its enactor
+ * takes both, dobfs_enactor.cuh:397,569).  *enabled: traversal_mode 2 is available; *built: a transpose was built; *build_ms:
+ * what that cost.  Any out pointer may be NULL.  Call after init. */
+int grx_bfs_auto_inverse(grx_bfs *p, int build_if_directed, int *enabled, int *built, float *build_ms);
 /* Enactor tuning knobs (the reference exposes alpha/beta on its DOBFS command line, tests/dobfs/test_dobfs.cu:530-534):
  * alpha, beta as above; lite_factor: a top-down level runs without queue output when frontier_edges*alpha*lite_factor
  * exceeds the unexplored edges (0 disables); tail_edge_limit: levels with at most this many edges run inside the

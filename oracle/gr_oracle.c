@@ -692,7 +692,8 @@ int gro_pagerank(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t sr
     int32_t it = 0;
     int64_t alive = 0;
     for (int32_t v = 0; v < nodes; ++v) alive += deg[v] > 0;
-    while (alive > 0) {
+    for (;;) {                                       /* `while (done[0] < 0)`, pr_enactor.cuh:341: the first pass always runs, even
+                                                        over an empty queue (every vertex peeled: all ranks end at 0, iteration 1) */
         for (int32_t s = 0; s < nodes; ++s) {
             if (deg[s] <= 0) continue;
             const double c = (double)(float)((float)cur[s] / (float)deg[s]);   /* the GPU divides in float */
@@ -707,7 +708,7 @@ int gro_pagerank(const int32_t *ro, const int32_t *ci, int32_t nodes, int32_t sr
         }
         for (int32_t v = 0; v < nodes; ++v) { cur[v] = nxt[v]; nxt[v] = 0.0; }
         ++it;
-        if (active == 0 || it >= max_iter) break;
+        if (active == 0 || alive == 0 || it >= max_iter) break;
     }
     for (int32_t v = 0; v < nodes; ++v) rank_out[v] = cur[v];
     if (degrees_out) memcpy(degrees_out, deg, sizeof(int32_t) * (size_t)nodes);

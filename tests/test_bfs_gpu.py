@@ -378,10 +378,13 @@ def test_binned_advance_parity(min_edges, tail_limit):
             p.close()
 
 
-def test_c_abi_entry_point_picks_direction_optimizing_on_symmetric_input(capfd):
-    # gunrock_bfs_func on a graph that is its own inverse runs the direction-optimizing schedule (the reference's entry point is
-    # top-down only, bfs_app.cu:196-200); a directed graph, or a small one, stays top-down.  Labels are the oracle's either way.
-    for scale, und, expect in [(16, True, True), (16, False, False), (10, True, False)]:
+def test_c_abi_entry_point_picks_direction_optimizing(capfd):
+    # gunrock_bfs_func runs the direction-optimizing schedule (the reference's entry point is top-down only, bfs_app.cu:196-200;
+    # its DOBFS primitive takes the inverse graph from the caller, dobfs_enactor.cuh:397,569): on a graph that is its own inverse
+    # directly, on a directed graph over the transpose it builds on the device; a small graph stays top-down.  Labels are the
+    # oracle's either way.
+    for scale, und, expect in [(16, True, "symmetric input: direction-optimizing"), (16, False, "directed input: direction-optimizing"),
+                               (10, True, None)]:
         g = o.rmat_seeded(scale, 8 << scale, undirected=und)
         src, _ = o.highest_degree_node(g)
         for mark_pred, idem in [(False, True), (True, False)]:
@@ -390,7 +393,57 @@ def test_c_abi_entry_point_picks_direction_optimizing_on_symmetric_input(capfd):
             ref, _, _ = o.bfs(g, int(src))
             assert np.array_equal(labels, ref)
             out = capfd.readouterr().out
-            assert ("direction-optimizing traversal" in out) == expect, out
+            if expect is None:
+                assert "direction-optimizing traversal" not in out, out
+            else:
+                assert expect in out, out
+
+
+def _oriented(g, keep):
+    """Sub-graph of g with the edges (f, t) for which keep(f, t) holds (rows stay sorted and duplicate-free)."""
+    froms = np.repeat(np.arange(g.nodes, dtype=np.int64), np.diff(g.row_offsets))
+    tos = g.col_indices.astype(np.int64)
+    m = keep(froms, tos)
+    ro = np.zeros(g.nodes + 1, dtype=np.int32)
+    np.cumsum(np.bincount(froms[m], minlength=g.nodes), out=ro[1:])
+    return o.Csr(g.nodes, ro, g.col_indices[m].astype(np.int32))
+
+
+@pytest.mark.parametrize("shape", ["downward", "upward", "mixed"])
+def test_symmetry_check_sees_one_way_edges(shape, capfd):
+    # ADVICE r2: a graph whose unmirrored edges all run from a higher to a lower id ({1 -> 0} is the smallest) must not pass as
+    # symmetric -- out-lists would be taken for in-lists, sinks would be preloaded as visited and never labelled.  >= 65536 edges
+    # so gunrock_bfs_func takes the direction-optimizing branch; expected: the device-built inverse, labels = oracle.
+    g0 = o.rmat_seeded(15, 8 << 15, undirected=True)
+    if shape == "downward":
+        g = _oriented(g0, lambda f, t: f > t)
+    elif shape == "upward":
+        g = _oriented(g0, lambda f, t: f < t)
+    else:  # mirrored pairs below 4096, one-way (downward) edges elsewhere
+        g = _oriented(g0, lambda f, t: (f > t) | ((f < 4096) & (t < 4096)))
+    assert g.edges >= 1 << 16
+    deg = np.diff(g.row_offsets)
+    for src in (int(np.argmax(deg)), g.nodes - 1, 0):
+        capfd.readouterr()
+        labels = ga.gunrock_bfs(g.nodes, g.row_offsets, g.col_indices, src=src, mark_pred=False, idempotence=True)
+        out = capfd.readouterr().out
+        ref, _, _ = o.bfs(g, src)
+        assert np.array_equal(labels, ref), shape
+        assert "directed input: direction-optimizing" in out, out
+    # phase-level entry: same decision
+    p = ga.BfsProblem(mark_pred=True, idempotence=False).init(g.nodes, g.row_offsets, g.col_indices)
+    try:
+        enabled, built, _ = p.auto_inverse()
+        assert enabled and built
+        src = int(np.argmax(deg))
+        p.reset(src)
+        p.enact(src, traversal_mode=2)
+        labels, preds = p.extract()
+        ref, _, _ = o.bfs(g, src)
+        assert np.array_equal(labels, ref)
+        assert o.check_bfs_preds(g, src, labels, preds) == 0
+    finally:
+        p.close()
 
 
 def test_instrumented_enactor_reports_cta_duty():

@@ -63,3 +63,22 @@ def test_test_bfs_cli_rmat_matches_reference_graph_size():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Graph: 1024 nodes, 997 edges" in out.stdout              # libc R-MAT golden
     assert "Label Validity: \nCORRECT" in out.stdout
+
+
+@pytest.mark.parametrize("flags", [["--undirected", "--src=566"], ["--src=0"], ["--undirected", "--src=7134"]])
+def test_user_functor_with_only_the_reference_methods(flags):
+    # a user-written problem + functor with ONLY CondEdge / ApplyEdge / CondFilter / ApplyFilter (the reference's
+    # non-idempotent atomicCAS claim, bfs_functor.cuh:49-117, restated) drives advance::LaunchKernel + filter::LaunchKernel level
+    # by level like codesnaps/bfs/bfs_enactor.cuh:41-62 -- no engine hook defined -- and matches the in-program CPU BFS.
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "user_functor", "-s"])
+    src = open(os.path.join(ROOT, "examples", "user_functor.hip")).read()
+    code = src.split("struct DepthFunctor {")[1].split("};")[0]
+    for hook in ("ScreenEdge", "IssueEdge", "ResolveEdge", "SourceData", "ApplyEdgeWave", "ReduceValue", "IssueFilter"):
+        assert hook not in code
+    out = _run([os.path.join(ROOT, "examples", "user_functor"), "market", os.path.join(ROOT, "tests", "golden", "bips98_606.mtx")] + flags)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Label Validity: \nCORRECT" in out.stdout and "TEST PASSED" in out.stdout
+    m = re.search(r"search depth: GPU (\d+), CPU (\d+)", out.stdout)
+    assert m and m.group(1) == m.group(2), out.stdout
+    if flags == ["--undirected", "--src=566"]:
+        assert int(m.group(1)) == 18                                  # 19 levels from vertex 566 = deepest label 18

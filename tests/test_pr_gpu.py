@@ -88,6 +88,21 @@ def test_rmat_parity(scale, undirected):
     p.close()
 
 
+@pytest.mark.parametrize("shape", ["downward", "mixed"])
+def test_c_abi_does_not_take_one_way_edges_for_symmetric(shape):
+    # with unmirrored edges that all run from a higher to a lower id the old symmetry test said "symmetric" and
+    # gunrock_pr_func pulled ranks over the OUT-lists.  Expected: the transpose is built, ranks = oracle.
+    g0 = o.rmat_seeded(13, 8 << 13, undirected=True)
+    froms = np.repeat(np.arange(g0.nodes, dtype=np.int64), np.diff(g0.row_offsets))
+    tos = g0.col_indices.astype(np.int64)
+    keep = (froms > tos) if shape == "downward" else ((froms > tos) | ((froms < 2048) & (tos < 2048)))
+    ro = np.zeros(g0.nodes + 1, dtype=np.int32)
+    np.cumsum(np.bincount(froms[keep], minlength=g0.nodes), out=ro[1:])
+    g = o.Csr(g0.nodes, ro, g0.col_indices[keep])
+    ids, ranks = ga.gunrock_pr(g.nodes, g.row_offsets, g.col_indices, src=-1, delta=0.85, error=0.0, max_iter=10)
+    _check_ranks(g, ids, ranks, -1, 0.85, 0.0, 10)
+
+
 def test_directed_graph_needs_its_inverse():
     # a directed chain with a sink: peeling removes everything but a 2-cycle; CSC given explicitly on the device
     import torch
@@ -109,9 +124,24 @@ def test_directed_graph_needs_its_inverse():
 
 
 def test_edge_cases():
-    g = o.Csr(3, [0, 0, 0, 0], [])                                     # no edges at all: nothing survives, no iteration runs
-    ids, ranks = ga.gunrock_pr(3, g.row_offsets, np.zeros(0, np.int32), src=-1)
-    assert sorted(ids.tolist()) == [0, 1, 2] and np.allclose(ranks, 0.15)
+    g = o.Csr(3, [0, 0, 0, 0], [])                                     # no edges at all: nothing survives; the reference still runs one
+    ids, ranks = ga.gunrock_pr(3, g.row_offsets, np.zeros(0, np.int32), src=-1)   # pass over its empty queue, which zeroes every rank
+    assert sorted(ids.tolist()) == [0, 1, 2] and np.allclose(ranks, 0.0)            # (pr_enactor.cuh:341,478-482)
+    ref, _, iters = o.pagerank(g, -1, 0.85, 0.01, 20)
+    assert np.allclose(ref, 0.0) and iters == 1
+    # a DAG: peeling removes every vertex round by round
+    rows = np.array([0, 0, 1, 2, 2, 3], dtype=np.int32)
+    cols = np.array([1, 2, 3, 3, 4, 4], dtype=np.int32)
+    hg = ga.HostGraph.from_coo(5, rows, cols)
+    g = o.Csr(5, np.array(hg.row_offsets), np.array(hg.col_indices))
+    p = ga.PrProblem().init(g.nodes, g.row_offsets, g.col_indices)
+    p.set_inverse_graph(build=True)
+    p.reset(-1, 0.85, 0.01)
+    p.enact(20)
+    ids, ranks = p.extract()
+    st = p.stats()
+    p.close()
+    assert np.allclose(ranks, 0.0) and st["iterations"] == 1 and st["surviving_nodes"] == 0
     hub = 5000                                                          # one list far longer than a wave's share, both directions
     rows = np.concatenate([np.zeros(hub - 1, np.int32), np.arange(1, hub, dtype=np.int32)])
     cols = np.concatenate([np.arange(1, hub, dtype=np.int32), np.zeros(hub - 1, np.int32)])

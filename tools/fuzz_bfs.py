@@ -53,20 +53,24 @@ while time.time() < t_end:
     if symmetric is None:
         ro, ci = np.asarray(g.row_offsets), np.asarray(g.col_indices)
         src_of = np.repeat(np.arange(g.nodes), np.diff(ro))
-        fwd = set(zip(src_of.tolist(), ci.tolist())) if g.edges < 200000 else None
-        symmetric = fwd is not None and all((b, a) in fwd for a, b in fwd)
+        key = src_of.astype(np.int64) * g.nodes + ci
+        symmetric = bool(np.array_equal(np.sort(key), np.sort(ci.astype(np.int64) * g.nodes + src_of)))
     deg = np.diff(g.row_offsets)
     for mark_pred in (False, True):
         p = ga.BfsProblem(mark_pred, bool(rng.integers(0, 2))).init(g.nodes, g.row_offsets, g.col_indices)
-        modes = [0, 1] + ([2] if symmetric else [])
-        if symmetric:
+        modes = [0, 1, 2]
+        if symmetric and rng.integers(0, 2):
             p.set_inverse_graph()
+        else:  # what gunrock_bfs_func does: symmetry check on the device, transpose built there for a directed graph
+            enabled, built, _ = p.auto_inverse()
+            if not enabled or built == bool(symmetric):
+                print("AUTO-INVERSE WRONG", name, "n", g.nodes, "m", g.edges, "symmetric", symmetric, "enabled", enabled, "built", built); sys.exit(1)
         if rng.integers(0, 2):
             p.set_tuning(tail_edge_limit=int(rng.choice([0, 64, 1024, 8192])))
             p.set_twc_limit(int(rng.choice([0, 16, 500, 8192, 1 << 20])))
             p.set_persistent_limit(int(rng.choice([0, 1 << 12, 1 << 20])))
             p.set_binned_min_edges(int(rng.choice([0, 1, 1000, 1 << 23])))
-            if symmetric:
+            if True:
                 p.set_head_pass(int(rng.choice([-1, 1, 1000])), int(rng.choice([-1, 0])))
         srcs = [int(np.argmax(deg)), int(rng.integers(0, g.nodes)), int(rng.integers(0, g.nodes))]
         for src in srcs:
