@@ -29,6 +29,7 @@ struct CcRunner {
     virtual void Stats(long long &edge_sweeps, long long &vertex_sweeps, long long &launches, double &kernel_ms) = 0;
     virtual hipError_t Extract(int *ids, unsigned *num_components) = 0;
     virtual int *DeviceIds() = 0;
+    virtual int Mirrored() = 0;
 };
 
 template <bool INSTR>
@@ -80,6 +81,7 @@ struct CcRunnerT : CcRunner {
         return rc;
     }
     int *DeviceIds() override { return problem.data_slices ? problem.data_slices[0]->d_component_ids : nullptr; }
+    int Mirrored() override { return problem.data_slices ? problem.data_slices[0]->symmetric : 0; }
 };
 
 }  // namespace
@@ -136,6 +138,13 @@ int grx_cc_stats(grx_cc *p, long long *edge_sweeps, long long *vertex_sweeps, lo
     if (vertex_sweeps) *vertex_sweeps = vs;
     if (kernel_launches) *kernel_launches = l;
     if (kernel_ms) *kernel_ms = k;
+    return 0;
+}
+
+int grx_cc_mirrored(grx_cc *p, int *mirrored)
+{
+    if (!p || !mirrored) return -1;
+    *mirrored = p->runner->Mirrored();
     return 0;
 }
 

@@ -180,6 +180,9 @@ int grx_cc_enact(grx_cc *p, int max_grid_size, float *elapsed_ms);
  * roofline figure -- plus, when instrumented, kernel launches and their summed time */
 int grx_cc_stats(grx_cc *p, long long *edge_sweeps, long long *vertex_sweeps, long long *kernel_launches, double *kernel_ms);
 /* CCProblem::Extract(h_component_ids) (reference cc_problem.cuh:144-175); num_components = #{v: id[v] == v} */
+/* *mirrored = 1 when Init found every edge (f, t), f < t, mirrored by (t, f): the hooking sweeps then park that orientation on first
+ * sight (its mirror performs the identical root comparison), i.e. from the second edge sweep on half of the edges are skipped */
+int grx_cc_mirrored(grx_cc *p, int *mirrored);
 int grx_cc_extract(grx_cc *p, int *h_component_ids, unsigned *num_components);
 int grx_cc_device_results(grx_cc *p, int **d_component_ids);
 void grx_cc_destroy(grx_cc *p);

@@ -199,3 +199,76 @@ def test_sssp_on_a_real_graph_when_provided():
         ref, _ = o.sssp(g, src, w)
         assert np.array_equal(dist_, ref)
         assert o.check_sssp_preds(g, src, dist_, preds, w) == 0
+
+
+# ---- BASELINE config 3's graph class: DIRECTED, soc-LiveJournal1's size (4.85 M vertices / 69.0 M directed edges; the file is
+#      unobtainable offline).  Stand-in: R-MAT over 2^22 ids, not mirrored, pair count chosen for ~69 M edges after dedup -- the
+#      same graph `bench.py --graph lj` times.  Small enough for the oracle: everything here is compared BIT FOR BIT. ----
+LJ_SCALE, LJ_PAIRS = 22, 73_400_000
+
+
+@pytest.fixture(scope="module")
+def lj_standin():
+    from oracle import gr_oracle as o
+    rows, cols = devgraph.rmat_tuples_device(LJ_SCALE, LJ_PAIRS, 0x6772)
+    ro, ci = devgraph.csr_from_tuples_device(1 << LJ_SCALE, rows, cols, undirected=False)
+    del rows, cols
+    n, m = ro.shape[0] - 1, int(ci.shape[0])
+    assert 60_000_000 < m < 75_000_000, m
+    h_ro, h_ci = devgraph.to_host_csr(ro, ci)
+    g = o.Csr(n, h_ro, h_ci)
+    # really directed: a good share of the edges has no mirror
+    src_of = torch.repeat_interleave(torch.arange(n, device="cuda", dtype=torch.int64), (ro[1:] - ro[:-1]).long())
+    keys = (src_of << 32) | ci.long()
+    rev = (ci.long() << 32) | src_of
+    pos = torch.searchsorted(keys, rev).clamp_(max=keys.shape[0] - 1)
+    mirrored = float((keys[pos] == rev).double().mean())
+    assert mirrored < 0.5, mirrored
+    return ro, ci, n, m, g
+
+
+def test_directed_livejournal_standin_bfs_direction_optimizing(lj_standin):
+    # a directed input reaches the direction-optimizing path through the inverse graph built on the device
+    # (grx_bfs_auto_inverse = what gunrock_bfs_func does; reference DOBFS takes the inverse from its caller, dobfs_enactor.cuh:397,569)
+    from oracle import gr_oracle as o
+    ro, ci, n, m, g = lj_standin
+    src, _ = devgraph.largest_degree_source(ro)
+    sources = [src] + devgraph.seeded_sources(ro, 3)
+    for mark_pred, idem in [(False, True), (True, False)]:
+        p = ga.BfsProblem(mark_pred=mark_pred, idempotence=idem, instrument=True).init_device(n, m, ro.data_ptr(), ci.data_ptr())
+        enabled, built, build_ms = p.auto_inverse()
+        assert enabled and built and build_ms > 0
+        for s in sources:
+            ref, _, _ = o.bfs(g, s)
+            for mode in (2, 0):
+                p.reset(s)
+                p.enact(s, traversal_mode=mode)
+                labels, preds = p.extract()
+                assert np.array_equal(labels, ref), (s, mode)
+                if mark_pred:
+                    assert o.check_bfs_preds(g, s, labels, preds) == 0
+                if mode == 2 and s == src:
+                    assert any(r["kind"] == 1 for r in p.level_trace()), "the hub search never turned bottom-up"
+        p.close()
+
+
+@pytest.mark.parametrize("delta_factor", [16, 32])                    # sssp_problem.cuh:189 and tests/sssp/ppopp-test.sh:5
+def test_directed_livejournal_standin_sssp(lj_standin, delta_factor):
+    from oracle import gr_oracle as o
+    ro, ci, n, m, g = lj_standin
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x6772)
+    w = torch.randint(1, 65, (m,), generator=gen, device="cuda", dtype=torch.int32)
+    h_w = w.cpu().numpy().astype(np.uint32)
+    src, _ = devgraph.largest_degree_source(ro)
+    deg = (ro[1:] - ro[:-1]).double()
+    delta = (int(float(w.double().mean())) * 32.0 / max(float(int(deg.mean())), 1.0)) * delta_factor   # SSSPProblem::EstimatedDelta x factor
+    ref, _ = o.sssp(g, src, h_w)
+    p = ga.SsspProblem(mark_pred=True).init_device(n, m, ro.data_ptr(), ci.data_ptr(), w.data_ptr(), delta)
+    p.reset(src)
+    p.enact(src)
+    dist_, preds = p.extract()
+    p.close()
+    assert np.array_equal(dist_, ref)
+    assert o.check_sssp_preds(g, src, dist_, preds, h_w) == 0
+    assert int((ref != 0xFFFFFFFF).sum()) > n // 4                   # the search covers a large part of the graph
