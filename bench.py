@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--lite-factor", type=float, default=-1.0)
     ap.add_argument("--head-pass-min", type=int, default=-1, help="heads-then-rest level: min frontier edges (-1 auto, 0 off)")
     ap.add_argument("--head-pass-max", type=int, default=-1, help="heads-then-rest level: max frontier edges (-1 auto, 0 none)")
+    ap.add_argument("--tail-edge-limit", type=int, default=-1, help="levels up to this many edges run in the one-workgroup tail kernel (-1 = library default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="named enactor knob (grx_bfs_set_option), repeatable")
     ap.add_argument("--traversal-mode", type=int, default=2,
                     help="0 = load-balanced top-down only, 2 = direction-optimizing (default)")
     ap.add_argument("--graph", choices=["rmat", "lj"], default=None,
@@ -240,8 +242,10 @@ def bench_single(args, torch, ga, devgraph, device_index):
     else:                             # what gunrock_bfs_func does for a directed input: transpose built on the device (outside Enact)
         enabled, built, inverse_build_ms = prob.auto_inverse()
         assert enabled and built
-    prob.set_tuning(args.alpha, args.beta, args.lite_factor)
+    prob.set_tuning(args.alpha, args.beta, args.lite_factor, args.tail_edge_limit)
     prob.set_head_pass(args.head_pass_min, args.head_pass_max)
+    for kv in args.opt:
+        prob.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     d_labels, _ = prob.device_results()
     labels_t = devgraph.as_tensor(d_labels, n)
 
@@ -294,8 +298,10 @@ def bench_single(args, torch, ga, devgraph, device_index):
         iprob.set_inverse_graph()
     else:
         iprob.auto_inverse()
-    iprob.set_tuning(args.alpha, args.beta, args.lite_factor)
+    iprob.set_tuning(args.alpha, args.beta, args.lite_factor, args.tail_edge_limit)
     iprob.set_head_pass(args.head_pass_min, args.head_pass_max)
+    for kv in args.opt:
+        iprob.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel / BottomUpSparseKernel",
              2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
              4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel",

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "grx_bfs_set_persistent_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_twc_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_binned_min_edges": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "grx_bfs_set_label_deferral": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "grx_bfs_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "grx_bfs_set_cooperative_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "grx_bfs_set_head_pass": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "grx_bfs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
@@ -157,6 +159,7 @@ _SIGNATURES = {
     "grx_pbfs_bitmap_to_queue": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "grx_pbfs_labels": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "grx_pbfs_preds": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_rccl_load": (C.c_int, []),
     "grx_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "grx_pbfs_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p]),
     "grx_pbfs_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -341,6 +344,16 @@ class BfsProblem:
 
     def set_head_pass(self, min_edges=-1, max_edges=-1):
         _check(lib().grx_bfs_set_head_pass(self._h, int(min_edges), int(max_edges)), "grx_bfs_set_head_pass")
+        return self
+
+    def set_option(self, name, value):
+        """Named enactor tuning knob (include/gunrock/gunrock_mi355x.h grx_bfs_set_option); results never depend on them."""
+        _check(lib().grx_bfs_set_option(self._h, name.encode(), float(value)), "grx_bfs_set_option(%s)" % name)
+        return self
+
+    def set_label_deferral(self, enabled=-1, mask_limit=0):
+        """Deferred labels of direction-optimizing searches (one emit pass at the end of Enact); effective at the next reset."""
+        _check(lib().grx_bfs_set_label_deferral(self._h, int(enabled), int(mask_limit)), "grx_bfs_set_label_deferral")
         return self
 
     def set_binned_min_edges(self, min_edges):

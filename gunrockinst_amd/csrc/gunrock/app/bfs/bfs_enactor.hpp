@@ -102,7 +102,7 @@ class BFSEnactor : public EnactorBase {
     template <typename BFSProblem, typename BfsFunctor>
     hipError_t RunTail(BFSProblem *problem, long long &iteration, int &selector, unsigned &queue_length, unsigned &queue_edges,
                        long long &unexplored_edges, hipStream_t stream, bool persistent = false, double switch_factor = 0.0,
-                       bool frontier_size_unknown = false, bool twc = false)
+                       bool frontier_size_unknown = false, bool twc = false, bool closing = false)
     {
         typedef typename BFSProblem::VertexId VertexId;
         typedef typename BFSProblem::SizeT SizeT;
@@ -150,6 +150,9 @@ class BFSEnactor : public EnactorBase {
         } else if ((retval = oprtr::advance::LaunchTailLevels<TailPolicy, BFSProblem, BfsFunctor>(t, *problem->data_slices[0],
                                                                                                    stream)))
             return retval;
+        // closing = this launch usually ends the search (the levels after the return to top-down): the deferred labels' emit pass
+        // is queued behind it without waiting for the read-back that confirms it -- one host round trip less per search
+        if (closing && (retval = problem->EmitLabelsSpeculative(stream))) return retval;
         if (INSTRUMENT && (retval = InstrumentEnd(stream))) return retval;
         if ((retval = work_progress.GetAll(stream))) return retval;
         if (persistent && work_progress.HostBarrierTimedOut())
@@ -160,6 +163,7 @@ class BFSEnactor : public EnactorBase {
         selector ^= (done & 1);
         queue_length = util::TailCount(work_progress.h_tail[iteration & 3]);
         queue_edges = util::TailEdges(work_progress.h_tail[iteration & 3]);
+        if (queue_length > 0) problem->emit_current = false;  // the search goes on: whatever it finds now needs another pass
         // the loop head already counted the first level's frontier; add the rest
         enactor_stats.total_queued += static_cast<long long>(work_progress.h_sums[0]);
         enactor_stats.total_edges_queued += static_cast<long long>(work_progress.h_sums[1]);
@@ -183,7 +187,10 @@ class BFSEnactor : public EnactorBase {
         GraphSlice<VertexId, SizeT, Value> *gs = problem->graph_slices[0];
         typename BFSProblem::DataSlice *ds = problem->data_slices[0];
         hipStream_t stream = gs->stream;
-        if (src < 0 || src >= problem->nodes) return retval;
+        if (src < 0 || src >= problem->nodes) return problem->EmitLabels(stream);
+        // deferred labels (bfs_problem.hpp): vertex-ordered sweeps keep their output bitmap instead of storing labels
+        const bool deferring = dobfs && problem->labels_deferred;
+        ds->defer_labels = deferring ? 1 : 0;
 
         unsigned queue_length = problem->SourceDegree() > 0 ? 1u : 0u;
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
@@ -196,12 +203,13 @@ class BFSEnactor : public EnactorBase {
         const int conv_grid = cu_count * GRX_CONV_GRID_MULT;
         const size_t mask_bytes = sizeof(unsigned) * static_cast<size_t>(problem->MaskWords() + 2);
         long long unexplored_edges = problem->edges;
-        // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_frontier_mask[1])
+        // (direction-optimizing: BFSProblem::Reset left "visited before the search" in d_snapshot)
         bool bottom_up = false;  // direction of the frontier representation: queue (false) or bitmap (true)
         bool force_bottom_up = false; // the last level ran count-only: its output exists only as a bitmap (already built)
         bool queue_emitted = false;   // the last (compacting) bottom-up sweep also wrote its finds to queue[selector] + ring slot
-        bool snapshot_valid = true;  // d_frontier_mask[1] holds "visited before the last top-down level" (Reset seeds it)
-        int cur_mask = 0;
+        bool snapshot_valid = true;  // d_snapshot holds "visited before the last top-down level" (Reset seeds it)
+        bool out_slot_clean = false; // the last bottom-up read-back cleared the ring slot a bitmap -> queue conversion would fill
+        int cur_mask = 0;            // index into the pool of frontier bitmaps (BFSProblem::AcquireMask)
         int selector = 0;
         long long iteration = 0;
         // bottom-up sweep: frontier = d_frontier_mask[in_mask], finds -> d_frontier_mask[out_mask]; heads_only = probe the
@@ -235,7 +243,8 @@ class BFSEnactor : public EnactorBase {
                 typedef oprtr::advance::BitmapLookup<VertexId> L;
                 // Emitting costs a flush (row extents, scan, writes) per workgroup, so only when this level will probably be the
                 // last bottom-up one: its input frontier is already within 32x of the switch-back threshold.
-                if (!heads_only && static_cast<double>(queue_length) * problem->beta < 32.0 * static_cast<double>(problem->nodes)) {
+                if (!heads_only && static_cast<double>(queue_length) * problem->beta <
+                                       static_cast<double>(problem->emit_queue_factor) * static_cast<double>(problem->nodes)) {
                     // also emit the finds as queue[selector] (tail in this level's output ring slot): a switch back to
                     // top-down then starts from it directly.  Fewer workgroups: each ends with one packed atomic on the slot.
                     bargs.queue_out = gs->frontier_queues[selector];
@@ -277,27 +286,29 @@ class BFSEnactor : public EnactorBase {
             ds->lite = 0;
             return rc;
         };
-        // closing pass of a count-only level: bytes -> d_frontier_mask[0] (| d_merge), visited, labels, count (wide tail)
-        auto launch_fresh_pass = [&](const unsigned long long *d_before, const unsigned long long *d_merge) -> hipError_t {
+        // closing pass of a count-only level: bytes -> d_frontier_mask[out_mask] (| d_merge), visited, labels (or the bitmap is kept
+        // for the deferred labels), count (wide tail)
+        auto launch_fresh_pass = [&](const unsigned long long *d_before, const unsigned long long *d_merge, int out_mask) -> hipError_t {
             const long long words64 = (static_cast<long long>(problem->nodes) + 63) / 64;
             long long fgrid = ((words64 + 15) / 16 + 3) / 4;  // 16 words per wave step, 4 waves per workgroup
             if (fgrid > cu_count * 4) fgrid = cu_count * 4;
             hipLaunchKernelGGL((oprtr::advance::FreshToBitmapKernel<VertexId>), dim3(static_cast<unsigned>(fgrid)), dim3(256), 0, stream,
                                ds->d_fresh, static_cast<long long>(problem->nodes), reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
-                               d_before, reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), ds->d_labels,
-                               static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_wide,
+                               d_before, reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[out_mask]),
+                               deferring ? static_cast<VertexId *>(nullptr) : ds->d_labels, static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_wide,
                                d_merge);
+            if (deferring) problem->KeepMask(out_mask, static_cast<VertexId>(iteration + 1));
             return util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__);
         };
-        // frontier queue -> d_frontier_mask[0]
-        auto queue_to_mask = [&]() -> hipError_t {
+        // frontier queue -> d_frontier_mask[out_mask]
+        auto queue_to_mask = [&](int out_mask) -> hipError_t {
             hipError_t rc;
             if (!snapshot_valid) {  // after a multi-level kernel the snapshot is several levels old: rebuild from the queue
-                if ((rc = util::GRError(hipMemsetAsync(ds->d_frontier_mask[0], 0, mask_bytes, stream),
+                if ((rc = util::GRError(hipMemsetAsync(ds->d_frontier_mask[out_mask], 0, mask_bytes, stream),
                                         "BFSEnactor hipMemsetAsync frontier mask failed", __FILE__, __LINE__)))
                     return rc;
                 hipLaunchKernelGGL((oprtr::advance::QueueToBitmapKernel<VertexId, SizeT>), dim3(conv_grid), dim3(256), 0, stream,
-                                   gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length), ds->d_frontier_mask[0]);
+                                   gs->frontier_queues[selector].v, static_cast<SizeT>(queue_length), ds->d_frontier_mask[out_mask]);
                 return util::GRError("QueueToBitmapKernel launch failed", __FILE__, __LINE__);
             }
             // the frontier is exactly what the last top-down level added to the visited bitmap (zero-degree discoveries
@@ -305,8 +316,8 @@ class BFSEnactor : public EnactorBase {
             const long long words64 = static_cast<long long>(problem->MaskWords()) / 2;
             hipLaunchKernelGGL(oprtr::advance::BitmapDiffKernel, dim3(conv_grid), dim3(256), 0, stream,
                                reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
-                               reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]),
-                               reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[0]), words64);
+                               reinterpret_cast<const unsigned long long *>(ds->d_snapshot),
+                               reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[out_mask]), words64);
             return util::GRError("BitmapDiffKernel launch failed", __FILE__, __LINE__);
         };
         while (queue_length > 0) {
@@ -331,8 +342,11 @@ class BFSEnactor : public EnactorBase {
                 enactor_stats.total_edges_queued += queue_edges;
                 unexplored_edges -= queue_edges;
                 ds->iteration = static_cast<VertexId>(iteration);
-                if ((retval = queue_to_mask())) break;              // frontier -> d_frontier_mask[0]
-                if ((retval = launch_bottom_up(0, 1, 1))) break;    // finds -> d_frontier_mask[1] (the snapshot is spent)
+                int front_mask = 0, heads_mask = 0, out_mask = 0;
+                if ((retval = problem->AcquireMask(stream, front_mask))) break;
+                if ((retval = queue_to_mask(front_mask))) break;                                 // frontier -> bitmap
+                if ((retval = problem->AcquireMask(stream, heads_mask, front_mask))) break;
+                if ((retval = launch_bottom_up(front_mask, heads_mask, 1))) break;               // the heads' finds
                 oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
                 args.in = gs->frontier_queues[selector];
                 args.out = gs->frontier_queues[selector ^ 1];
@@ -345,10 +359,11 @@ class BFSEnactor : public EnactorBase {
                 args.d_overflow = work_progress.d_overflow;
                 if ((retval = launch_count_only(args))) break;
                 // the advance did not touch the visited bitmap, so the bitmap itself is "visited before" for the closing pass
+                if ((retval = problem->AcquireMask(stream, out_mask, front_mask, heads_mask))) break;
                 if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
-                                                reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]))))
+                                                reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[heads_mask]), out_mask)))
                     break;
-                cur_mask = 0;
+                cur_mask = out_mask;
                 force_bottom_up = true;
                 snapshot_valid = false;
                 if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
@@ -358,12 +373,11 @@ class BFSEnactor : public EnactorBase {
                 continue;  // (selector unchanged: no queue was written)
             } else if (dobfs && !bottom_up &&
                 (force_bottom_up || static_cast<double>(queue_edges) * problem->alpha > static_cast<double>(unexplored_edges))) {
-                if (force_bottom_up) {  // the count-only level already left its discoveries in d_frontier_mask[0]
+                if (force_bottom_up) {  // the count-only level already left its discoveries in d_frontier_mask[cur_mask]
                     force_bottom_up = false;
-                    cur_mask = 0;
                 } else {  // queue -> bitmap
-                    if ((retval = queue_to_mask())) break;
-                    cur_mask = 0;
+                    if ((retval = problem->AcquireMask(stream, cur_mask))) break;
+                    if ((retval = queue_to_mask(cur_mask))) break;
                 }
                 bottom_up = true;
             } else if (dobfs && bottom_up &&
@@ -372,8 +386,10 @@ class BFSEnactor : public EnactorBase {
                 // this iteration's ring slot so the multi-level tail kernel can take over without a host round trip
                 if (!queue_emitted) {
                     unsigned long long *slot = work_progress.d_tail + (iteration & 3);
-                    if ((retval = util::GRError(hipMemsetAsync(slot, 0, sizeof(unsigned long long), stream),
-                                                "BFSEnactor clear tail failed", __FILE__, __LINE__)))
+                    // (normally the read-back of the last sweep has already zeroed this slot: a fill blit here cost ~10 us of host
+                    //  and device time between two kernels)
+                    if (!out_slot_clean && (retval = util::GRError(hipMemsetAsync(slot, 0, sizeof(unsigned long long), stream),
+                                                                   "BFSEnactor clear tail failed", __FILE__, __LINE__)))
                         break;
                     hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256),
                                        0, stream, ds->d_frontier_mask[cur_mask], problem->nodes,
@@ -387,7 +403,7 @@ class BFSEnactor : public EnactorBase {
                 // grid barrier) and carries on alone in workgroup 0 once the levels are small -- no host round trip between.
                 if ((retval = RunTail<BFSProblem, BfsFunctor>(problem, iteration, selector, queue_length, queue_edges,
                                                               unexplored_edges, stream, problem->persistent_edge_limit > 0, 0.0,
-                                                              true)))
+                                                              true, false, true)))
                     break;
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 2);
                 continue;  // the loop re-examines the frontier the tail kernel left (empty, or too large for it)
@@ -434,18 +450,29 @@ class BFSEnactor : public EnactorBase {
             enactor_stats.total_edges_queued += queue_edges;
             unexplored_edges -= queue_edges;
             ds->iteration = static_cast<VertexId>(iteration);
-            if (dobfs && !bottom_up) {
-                // snapshot of the visited bitmap before this top-down level (n/8 bytes, device to device)
-                if ((retval = util::GRError(hipMemcpyAsync(ds->d_frontier_mask[1], ds->d_visited_mask, mask_bytes,
-                                                           hipMemcpyDeviceToDevice, stream),
-                                            "BFSEnactor visited snapshot failed", __FILE__, __LINE__)))
-                    break;
+            // "Count-only" top-down level: when the search is about to turn bottom-up, the level's discoveries are needed
+            // only as a bitmap, so the frontier writer (row-offset gather, 12-byte queue entries), the claims and the scattered
+            // label stores are skipped; a closing sweep turns the flag bytes into the bitmap.
+            const bool lite = dobfs && !bottom_up && queue_edges > static_cast<unsigned>(problem->tail_edge_limit) &&
+                              static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges);
+            if (dobfs && !bottom_up && !lite) {
+                // snapshot of the visited bitmap before this top-down level (n/8 bytes): what a switch to bottom-up after it
+                // diffs against.  Own kernel: hipMemcpyAsync's blit path cost the host ~8 us more per call.  (A count-only
+                // level needs none: it does not touch the visited bitmap.)
+                const long long words64 = static_cast<long long>(problem->MaskWords()) / 2 + 1;
+                hipLaunchKernelGGL(oprtr::advance::BitmapCopyKernel, dim3(conv_grid), dim3(256), 0, stream,
+                                   reinterpret_cast<const unsigned long long *>(ds->d_visited_mask),
+                                   reinterpret_cast<unsigned long long *>(ds->d_snapshot), words64);
+                if ((retval = util::GRError("BitmapCopyKernel launch failed", __FILE__, __LINE__))) break;
                 snapshot_valid = true;
             }
 
             if (bottom_up) {
-                if ((retval = launch_bottom_up(cur_mask, cur_mask ^ 1, 0))) break;
-                cur_mask ^= 1;
+                int out_mask = 0;
+                if ((retval = problem->AcquireMask(stream, out_mask, cur_mask))) break;
+                if ((retval = launch_bottom_up(cur_mask, out_mask, 0))) break;
+                if (deferring) problem->KeepMask(out_mask, static_cast<VertexId>(iteration + 1));
+                cur_mask = out_mask;
             } else {
                 oprtr::advance::AdvanceArgs<VertexId, SizeT> args;
                 args.in = gs->frontier_queues[selector];
@@ -458,16 +485,15 @@ class BFSEnactor : public EnactorBase {
                 args.d_tail_clear = work_progress.d_tail + ((iteration + 2) & 3);
                 args.d_overflow = work_progress.d_overflow;
                 args.d_duty = INSTRUMENT ? DutySlot() : nullptr;
-                // "Count-only" top-down level: when the search is about to turn bottom-up, the level's discoveries are needed
-                // only as a bitmap (visited now XOR visited before), so the frontier writer (row-offset gather, 12-byte queue
-                // entries) and the scattered label stores are skipped; the bottom-up sweep that follows labels them in order.
-                const bool lite = dobfs && snapshot_valid && queue_edges > static_cast<unsigned>(problem->tail_edge_limit) &&
-                                  static_cast<double>(queue_edges) * problem->alpha * problem->lite_factor > static_cast<double>(unexplored_edges);
                 if (lite) {
+                    int out_mask = 0;
+                    if ((retval = problem->AcquireMask(stream, out_mask))) break;
                     if ((retval = launch_count_only(args))) break;
-                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[1]), nullptr))) break;
-                    cur_mask = 0;
+                    // (the advance did not touch the visited bitmap: the bitmap itself is "visited before the level")
+                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask), nullptr, out_mask))) break;
+                    cur_mask = out_mask;
                     force_bottom_up = true;
+                    snapshot_valid = false;
                     if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                     ++iteration;
                     if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
@@ -493,10 +519,12 @@ class BFSEnactor : public EnactorBase {
                                                                                                expand_grid, apply_grid, stream);
                     if (retval) break;
                     // closing sweep: flag bytes -> labels (vertex order), visited bitmap, this level's discoveries as a bitmap ...
-                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask), nullptr))) break;
+                    int out_mask = 0;
+                    if ((retval = problem->AcquireMask(stream, out_mask))) break;
+                    if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask), nullptr, out_mask))) break;
                     // ... and as the next queue (vertex order, exact degrees), its packed tail in this level's output ring slot
                     hipLaunchKernelGGL((oprtr::advance::BitmapToQueueKernel<256, VertexId, SizeT>), dim3(conv_grid), dim3(256), 0,
-                                       stream, ds->d_frontier_mask[0], problem->nodes, gs->frontier_queues[selector ^ 1],
+                                       stream, ds->d_frontier_mask[out_mask], problem->nodes, gs->frontier_queues[selector ^ 1],
                                        work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_overflow, gs->d_row_offsets);
                     if ((retval = util::GRError("BitmapToQueueKernel launch failed", __FILE__, __LINE__))) break;
                 } else if ((retval = oprtr::advance::LaunchKernel<AdvancePolicy, BFSProblem, BfsFunctor>(
@@ -508,12 +536,16 @@ class BFSEnactor : public EnactorBase {
 
             ++iteration;
             if (bottom_up) {
-                if ((retval = work_progress.GetAll(stream))) break;
+                // (a sweep that emitted no queue leaves nothing in its output ring slot worth keeping: the read-back zeroes the
+                //  slot, so a bitmap -> queue conversion can follow without a clear of its own)
+                out_slot_clean = !queue_emitted;
+                if ((retval = work_progress.Sync(stream, queue_emitted ? 0u : (1u << (iteration & 3))))) break;
                 queue_length = util::TailCount(work_progress.box->wide);  // finds of the sweep
                 queue_edges = 0;
                 if (queue_emitted) {  // the ring slot holds the emitted queue's packed tail, not a count to add
                     if (work_progress.h_tail[util::WorkProgress::kAux] != 0) {  // a staging buffer overflowed: no usable queue
                         queue_emitted = false;
+                        out_slot_clean = false;  // (the slot holds the partial queue's tail)
                         if ((retval = work_progress.ClearAux(stream))) break;
                     }
                 } else {
@@ -527,6 +559,15 @@ class BFSEnactor : public EnactorBase {
         }
         enactor_stats.iteration = iteration;
         if (retval) return retval;
+        if (problem->labels_deferred) {  // every label of the search in one coalesced pass (bfs_problem.hpp EmitLabelsKernel)
+            if (INSTRUMENT && (retval = InstrumentBegin(stream))) return retval;
+            if ((retval = problem->EmitLabels(stream))) return retval;
+            if (INSTRUMENT) {
+                if ((retval = InstrumentEnd(stream))) return retval;
+                if ((retval = util::GRError(hipStreamSynchronize(stream), "BFSEnactor EmitLabels sync failed", __FILE__, __LINE__))) return retval;
+                InstrumentCollect(0, 0, 9);
+            }
+        }
         if (INSTRUMENT && (retval = DutyCollect(stream))) return retval;
 
         // (the loop's last read-back followed its last kernel, and SetTail cleared the flag of the previous search)

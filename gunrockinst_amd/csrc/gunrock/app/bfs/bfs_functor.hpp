@@ -88,9 +88,7 @@ struct BFSFunctor {
     static __device__ __forceinline__ void ApplyEdge(VertexId s_id, VertexId d_id, DataSlice *problem,
                                                      VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-#ifndef GRX_EXP_NO_LABELS
-        if (!problem->lite) problem->d_labels[d_id] = problem->iteration + 1;
-#endif  // (lite: FreshToBitmapKernel labels in vertex order)
+        if (!problem->lite) problem->d_labels[d_id] = problem->iteration + 1;  // (lite: FreshToBitmapKernel labels in vertex order)
         if (ProblemData::MARK_PREDECESSORS) problem->d_preds[d_id] = s_id;
     }
 

@@ -57,9 +57,11 @@ static __global__ void WithInEdgesCountKernel(const unsigned long long *d_never,
 }
 
 // Reset in one launch: 16-byte stores for labels / preds, the source patched in flight, queue entry 0 seeded.
+// fill_labels = 0: labels are deferred (BFSProblem::labels_deferred) -- only the source's label is written here and
+// EmitLabelsKernel writes every label once, at the end of Enact.
 template <typename VertexId, typename SizeT, bool PRED>
 __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *d_visited, const unsigned *d_never,
-                               unsigned *d_snapshot, long long nodes,
+                               unsigned *d_snapshot, int fill_labels, long long nodes,
                                long long mask_words, VertexId src, const SizeT *d_row_offsets,
                                util::Frontier<VertexId, SizeT> queue0, SizeT *h_src_row, unsigned long long *h_src_seq,
                                unsigned long long seq)
@@ -70,22 +72,23 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
     const long long nvec = nodes / 4;
     V4 *labels4 = reinterpret_cast<V4 *>(d_labels);
     V4 *preds4 = reinterpret_cast<V4 *>(d_preds);
-    for (long long k = tid; k < nvec; k += stride) {
-        V4 l = {-1, -1, -1, -1};
-        V4 p = {-2, -2, -2, -2};
-        if (src >= 0 && k == src / 4) {
-            l[src & 3] = 0;
-            p[src & 3] = -1;
+    if (fill_labels || PRED) {
+        for (long long k = tid; k < nvec; k += stride) {
+            V4 l = {-1, -1, -1, -1};
+            V4 p = {-2, -2, -2, -2};
+            if (src >= 0 && k == src / 4) {
+                l[src & 3] = 0;
+                p[src & 3] = -1;
+            }
+            if (fill_labels) labels4[k] = l;
+            if (PRED) preds4[k] = p;
         }
-#ifndef GRX_EXP_NO_LABELS
-        labels4[k] = l;
-#endif
-        if (PRED) preds4[k] = p;
+        for (long long i = nvec * 4 + tid; i < nodes; i += stride) {
+            if (fill_labels) d_labels[i] = (i == src) ? 0 : -1;
+            if (PRED) d_preds[i] = (i == src) ? -1 : -2;
+        }
     }
-    for (long long i = nvec * 4 + tid; i < nodes; i += stride) {
-        d_labels[i] = (i == src) ? 0 : -1;
-        if (PRED) d_preds[i] = (i == src) ? -1 : -2;
-    }
+    if (!fill_labels && tid == 0 && src >= 0) d_labels[src] = 0;
     for (long long w = tid; w < mask_words; w += stride)
     {
         const unsigned never = d_never ? d_never[w] : 0u;
@@ -108,6 +111,79 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
     }
 }
 
+// ---- deferred labels (direction-optimizing searches) ----
+// A bottom-up sweep or the closing pass of a count-only level finds its vertices in VERTEX order but only some of every 16:
+// writing their labels there is one partial 64-byte sector after the other (PMC, round 2: 2.3x write amplification, 34 us of
+// a 350 us scale-24 search), on top of the 64 MB fill of -1 at Reset.  BFS depth = the level whose frontier bitmap holds the
+// vertex, so those levels only KEEP their output bitmap (n/8 bytes each, a pool of kLevelMasks) and this kernel writes every
+// label of the search once, 16 bytes per lane, at the end of Enact:
+//   bit set in the bitmap of level L              -> L
+//   visited, in no kept bitmap, has in-edges       -> what a top-down kernel wrote (they label at discovery: few vertices)
+//   the source                                     -> 0 (Reset wrote it)
+//   otherwise                                      -> -1
+// FULL = false is the flush used when the pool runs out of bitmaps in the middle of a search: only the set bits are stored.
+constexpr int kLevelMasks = 12;
+
+template <typename VertexId>
+struct LevelMaskList {
+    const unsigned long long *mask[kLevelMasks];
+    VertexId label[kLevelMasks];
+    int count = 0;
+};
+
+// KMAX = bitmaps the kernel reads (entries past levels.count repeat entry 0: the same bit gives the same label).  All KMAX + 2
+// word loads of a lane are issued before the first is looked at -- with a run-time loop over the list every bitmap was its own
+// dependent round trip (33 us for the 64 MB of a scale-24 graph; the store stream alone is ~14 us).
+template <typename VertexId, bool FULL, int KMAX>
+__global__ __launch_bounds__(256) void EmitLabelsKernel(LevelMaskList<VertexId> levels, const unsigned long long *d_visited,
+                                                        const unsigned long long *d_never, long long nodes, VertexId src, VertexId *d_labels)
+{
+    typedef __attribute__((ext_vector_type(4))) int V4;
+    const long long quads = (nodes + 3) / 4;  // four consecutive vertices per lane: one 16-byte store
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long q = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const long long v0 = q * 4;
+        const long long w = v0 >> 6;
+        const int sh = static_cast<int>(v0 & 63);
+        unsigned long long mw[KMAX > 0 ? KMAX : 1];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) mw[k] = levels.mask[k][w];  // (the sixteen lanes of a word read the same address)
+        unsigned long long vis = 0, nev = 0;
+        if (FULL) {
+            vis = d_visited[w];
+            nev = d_never ? d_never[w] : 0ull;  // pre-marked "visited": never discovered
+        }
+        V4 out = {-1, -1, -1, -1};
+        unsigned covered = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned m = static_cast<unsigned>(mw[k] >> sh) & 0xFu;
+            covered |= m;
+            const VertexId l = levels.label[k];
+            if (m & 1u) out[0] = l;
+            if (m & 2u) out[1] = l;
+            if (m & 4u) out[2] = l;
+            if (m & 8u) out[3] = l;
+        }
+        if (FULL) {
+            unsigned keep = static_cast<unsigned>((vis & ~nev) >> sh) & 0xFu & ~covered;
+            if (src >= v0 && src < v0 + 4) keep |= 1u << (src - v0);
+            if (keep) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (((keep >> b) & 1u) && v0 + b < nodes) out[b] = d_labels[v0 + b];
+            }
+            if (v0 + 3 < nodes) *reinterpret_cast<V4 *>(d_labels + v0) = out;
+            else
+                for (int b = 0; b < 4 && v0 + b < nodes; ++b) d_labels[v0 + b] = out[b];
+        } else if (covered) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (((covered >> b) & 1u) && v0 + b < nodes) d_labels[v0 + b] = out[b];
+        }
+    }
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _MARK_PREDECESSORS,
           bool _ENABLE_IDEMPOTENCE, bool _USE_DOUBLE_BUFFER>
 struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
@@ -124,9 +200,11 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         unsigned *d_visited_mask = nullptr;   // 1 bit per vertex
         VertexId iteration = 0;               // current BSP level (labels written = iteration + 1)
         int lite = 0;                         // 1: count-only level: mark d_fresh[d] with a plain byte store, no claim, no label
+        int defer_labels = 0;                 // 1: sweeps in vertex order leave the labels to EmitLabelsKernel (their bitmaps are kept)
         unsigned char *d_fresh = nullptr;     // one byte per vertex, all zero between levels (direction-optimizing only)
         // direction-optimizing traversal (reference app/dobfs: d_frontier_map_in/out, dobfs_problem.cuh):
-        unsigned *d_frontier_mask[2] = {nullptr, nullptr};  // 1 bit per vertex: current / next frontier
+        unsigned *d_frontier_mask[kLevelMasks] = {};        // 1 bit per vertex: pool of frontier bitmaps (current / next / kept levels)
+        unsigned *d_snapshot = nullptr;                     // the visited bitmap as it was before the last top-down level
         unsigned *d_never_mask = nullptr;                   // vertices without in-edges: nothing can ever discover them
         unsigned *d_head_base = nullptr;                    // compacted heads: first entry of every 64-vertex word (bottom_up.hpp)
         int2 *d_inv_heads = nullptr;                        // first two in-neighbours per vertex (bottom_up.hpp)
@@ -153,6 +231,11 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // a bottom-up level runs the compacting sweep (BottomUpSparseKernel) when at most nodes / sparse_sweep_div such vertices
     // can still be unvisited (0 = never)
     int sparse_sweep_div = 16;
+    // ... and that sweep also writes its finds as the next top-down queue when its input frontier is within this factor of the
+    // switch-back threshold (frontier * beta < factor * nodes): the switch then needs no bitmap -> queue pass
+    float emit_queue_factor = 32.0f;
+    bool speculative_emit = true;  // deferred labels: the emit pass is queued right behind the closing top-down launch
+    int chain_sweeps = 1;          // bottom-up sweeps queued per host round trip
     long long HeadPassMin() const { return head_pass_min_edges >= 0 ? head_pass_min_edges : static_cast<long long>(this->edges) / 30 + 1; }
     long long HeadPassMax() const
     {
@@ -182,8 +265,9 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                 if (ds->d_labels) util::GRError(hipFree(ds->d_labels), "BFSProblem hipFree d_labels failed", __FILE__, __LINE__);
                 if (ds->d_preds) util::GRError(hipFree(ds->d_preds), "BFSProblem hipFree d_preds failed", __FILE__, __LINE__);
                 if (ds->d_visited_mask) util::GRError(hipFree(ds->d_visited_mask), "BFSProblem hipFree d_visited_mask failed", __FILE__, __LINE__);
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < kLevelMasks; ++i)
                     if (ds->d_frontier_mask[i]) util::GRError(hipFree(ds->d_frontier_mask[i]), "BFSProblem hipFree d_frontier_mask failed", __FILE__, __LINE__);
+                if (ds->d_snapshot) util::GRError(hipFree(ds->d_snapshot), "BFSProblem hipFree d_snapshot failed", __FILE__, __LINE__);
                 if (ds->d_never_mask) util::GRError(hipFree(ds->d_never_mask), "BFSProblem hipFree d_never_mask failed", __FILE__, __LINE__);
                 if (ds->d_fresh) util::GRError(hipFree(ds->d_fresh), "BFSProblem hipFree d_fresh failed", __FILE__, __LINE__);
                 if (ds->d_head_base) util::GRError(hipFree(ds->d_head_base), "BFSProblem hipFree d_head_base failed", __FILE__, __LINE__);
@@ -208,10 +292,12 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         DataSlice *ds = data_slices[0];
         ds->d_inv_row_offsets = d_inv_row_offsets;
         ds->d_inv_column_indices = d_inv_column_indices;
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kLevelMasks; ++i)
             if (!ds->d_frontier_mask[i])
                 GR_CHECK(hipMalloc(&ds->d_frontier_mask[i], sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)),
                          "BFSProblem hipMalloc d_frontier_mask failed");
+        if (!ds->d_snapshot)
+            GR_CHECK(hipMalloc(&ds->d_snapshot, sizeof(unsigned) * static_cast<size_t>(MaskWords() + 2)), "BFSProblem hipMalloc d_snapshot failed");
         // Static per graph: bit v set when v has no in-edge.  Reset preloads the visited bitmap with it, so the bottom-up
         // sweep skips those vertices (half of an R-MAT graph) without touching their row offsets, 64 at a time.
         if (!ds->d_never_mask)
@@ -343,6 +429,12 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             h_src_box->seq = 0;
         }
         ds->iteration = 0;
+        ds->defer_labels = 0;
+        // direction-optimizing problems defer the labels of their vertex-ordered sweeps: no fill here, one pass at the end of Enact
+        labels_deferred = direction_optimizing && defer_labels;
+        level_masks.count = 0;
+        mask_ring = 0;
+        emit_current = false;
         const bool valid = src >= 0 && src < this->nodes;
         const long long work = (static_cast<long long>(this->nodes) + 3) / 4;
         long long grid = (work + 255) / 256;
@@ -351,7 +443,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         ++reset_seq;
         hipLaunchKernelGGL((BfsResetKernel<VertexId, SizeT, MARK_PREDECESSORS>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream,
                            ds->d_labels, ds->d_preds, ds->d_visited_mask, direction_optimizing ? ds->d_never_mask : nullptr,
-                           direction_optimizing ? ds->d_frontier_mask[1] : nullptr, static_cast<long long>(this->nodes),
+                           direction_optimizing ? ds->d_snapshot : nullptr, labels_deferred ? 0 : 1, static_cast<long long>(this->nodes),
                            static_cast<long long>(MaskWords() + 2), valid ? src : static_cast<VertexId>(-1), gs->d_row_offsets,
                            gs->frontier_queues[0], h_src_box->row, &h_src_box->seq, reset_seq);
         GR_CHECK(hipGetLastError(), "BfsResetKernel launch failed");
@@ -393,6 +485,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         hipError_t retval = hipSuccess;
         DataSlice *ds = data_slices[0];
         hipStream_t stream = this->graph_slices[0]->stream;
+        GR_CHECK(EmitLabels(stream), "BFSProblem Extract: EmitLabels failed");  // (no-op after an Enact: it ends with this pass)
         GR_CHECK(hipStreamSynchronize(stream), "BFSProblem Extract sync failed");
         if (this->nodes > 0)
             GR_CHECK(hipMemcpy(h_labels, ds->d_labels, sizeof(VertexId) * static_cast<size_t>(this->nodes), hipMemcpyDeviceToHost),
@@ -401,6 +494,103 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipMemcpy(h_preds, ds->d_preds, sizeof(VertexId) * static_cast<size_t>(this->nodes), hipMemcpyDeviceToHost),
                      "BFSProblem hipMemcpy d_preds failed");
         return retval;
+    }
+
+    // ---- deferred labels: the kept level bitmaps of the running search ----
+    bool defer_labels = true;       // policy (off: every kernel labels at discovery, Reset fills -1)
+    bool emit_current = false;      // state: a speculative emit pass has run and no vertex has been discovered since
+    bool labels_deferred = false;   // state: d_labels is incomplete until EmitLabels has run (set by Reset, cleared by EmitLabels)
+    int level_mask_limit = kLevelMasks;  // bitmaps of the pool a search may use (tests shrink it to force mid-search flushes)
+    LevelMaskList<VertexId> level_masks; // (bitmap, label) of every kept level
+    int mask_ring = 0;
+
+    bool MaskKept(int idx) const
+    {
+        for (int k = 0; k < level_masks.count; ++k)
+            if (level_masks.mask[k] == reinterpret_cast<const unsigned long long *>(data_slices[0]->d_frontier_mask[idx])) return true;
+        return false;
+    }
+    // A bitmap of the pool that is neither kept nor one of the (up to two) the caller is still reading.  When every other one
+    // is kept, the kept levels are flushed into d_labels first (partial stores -- the price the deferral normally avoids).
+    hipError_t AcquireMask(hipStream_t stream, int &idx, int hold_a = -1, int hold_b = -1)
+    {
+        hipError_t retval = hipSuccess;
+        if (!data_slices[0]->d_frontier_mask[1]) {  // no pool (no inverse graph): the binned level's single bitmap
+            idx = 0;
+            return retval;
+        }
+        const int limit = level_mask_limit < 4 ? 4 : (level_mask_limit > kLevelMasks ? kLevelMasks : level_mask_limit);
+        for (int round = 0; round < 2; ++round) {
+            for (int t = 0; t < limit; ++t) {
+                const int cand = (mask_ring + t) % limit;
+                if (cand == hold_a || cand == hold_b || MaskKept(cand)) continue;
+                idx = cand;
+                mask_ring = (cand + 1) % limit;
+                return retval;
+            }
+            GR_CHECK(FlushLevelMasks(stream), "BFSProblem FlushLevelMasks failed");
+        }
+        return util::GRError(hipErrorInvalidValue, "BFSProblem: no free frontier bitmap", __FILE__, __LINE__);
+    }
+    void KeepMask(int idx, VertexId label)
+    {
+        level_masks.mask[level_masks.count] = reinterpret_cast<const unsigned long long *>(data_slices[0]->d_frontier_mask[idx]);
+        level_masks.label[level_masks.count] = label;
+        ++level_masks.count;
+    }
+    template <bool FULL>
+    hipError_t LaunchEmit(hipStream_t stream, VertexId src)
+    {
+        DataSlice *ds = data_slices[0];
+        long long grid = ((static_cast<long long>(this->nodes) + 3) / 4 + 255) / 256;  // one quad of vertices per thread
+        if (grid > (1 << 20)) grid = 1 << 20;
+        if (grid < 1) grid = 1;
+        LevelMaskList<VertexId> list = level_masks;
+        const int kmax = list.count == 0 ? 0 : (list.count <= 4 ? 4 : (list.count <= 8 ? 8 : kLevelMasks));
+        for (int k = list.count; k < kmax; ++k) {  // padding: entry 0 again
+            list.mask[k] = list.mask[0];
+            list.label[k] = list.label[0];
+        }
+        const unsigned long long *vis = reinterpret_cast<const unsigned long long *>(ds->d_visited_mask);
+        const unsigned long long *nev = reinterpret_cast<const unsigned long long *>(ds->d_never_mask);
+        const long long n = static_cast<long long>(this->nodes);
+        const dim3 g(static_cast<unsigned>(grid)), b(256);
+        if (kmax == 0) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 0>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+        else if (kmax == 4) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 4>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+        else if (kmax == 8) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 8>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+        else hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, kLevelMasks>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+        level_masks.count = 0;
+        return util::GRError(hipGetLastError(), "EmitLabelsKernel launch failed", __FILE__, __LINE__);
+    }
+    hipError_t FlushLevelMasks(hipStream_t stream)
+    {
+        if (level_masks.count == 0) return hipSuccess;
+        return LaunchEmit<false>(stream, static_cast<VertexId>(-1));
+    }
+    // The closing pass of a search whose Reset left the labels unfilled.
+    hipError_t EmitLabels(hipStream_t stream)
+    {
+        if (!labels_deferred) return hipSuccess;
+        labels_deferred = false;
+        if (emit_current) {  // a speculative pass already wrote them and nothing was discovered since
+            emit_current = false;
+            level_masks.count = 0;
+            return hipSuccess;
+        }
+        return LaunchEmit<true>(stream, (source >= 0 && source < this->nodes) ? source : static_cast<VertexId>(-1));
+    }
+    // The same pass queued BEFORE the host knows that the search is over (behind the launch that usually ends it): the kept
+    // bitmaps and the deferral stay as they are, so that a search that does go on simply ends with another pass -- the first
+    // one wrote nothing wrong (labels of levels that existed), the second one covers the rest.  The caller clears emit_current
+    // when anything is discovered after this.
+    hipError_t EmitLabelsSpeculative(hipStream_t stream)
+    {
+        if (!labels_deferred || !speculative_emit) return hipSuccess;
+        const LevelMaskList<VertexId> keep = level_masks;
+        const hipError_t rc = LaunchEmit<true>(stream, (source >= 0 && source < this->nodes) ? source : static_cast<VertexId>(-1));
+        level_masks = keep;
+        emit_current = true;
+        return rc;
     }
 
     VertexId source = -1;

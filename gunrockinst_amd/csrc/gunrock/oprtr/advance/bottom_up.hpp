@@ -52,6 +52,12 @@ __attribute__((unused)) static __global__ void BitmapDiffKernel(const unsigned l
         d_out[w] = d_now[w] ^ d_before[w];
 }
 
+__attribute__((unused)) static __global__ void BitmapCopyKernel(const unsigned long long *d_from, unsigned long long *d_to, long long words)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; w < words; w += stride) d_to[w] = d_from[w];
+}
+
 // ---- "fresh" byte flags -> bitmaps + labels (the closing pass of an atomic-free top-down level) ----
 // A count-only top-down level marks every unvisited destination with a plain one-byte store (duplicates are harmless,
 // nothing waits for a returned value; the same level with atomicOr claims was bound by the memory-side atomic rate).
@@ -90,12 +96,13 @@ __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, uns
         const unsigned long long mask = word & ~seen;
         unsigned mine = static_cast<unsigned>(mask >> (16 * quad)) & 0xFFFFu;
         const long long v0 = (step * 64 + lane) * 16;
-        while (mine) {
-            const int b = __builtin_ctz(mine);
-            mine &= mine - 1;
-#ifndef GRX_EXP_NO_LABELS
-            d_labels[v0 + b] = label;
-#endif
+        if (d_labels) {  // (kernel argument: uniform) nullptr = labels are deferred: the level's bitmap is kept and
+                         // EmitLabelsKernel (bfs_problem.hpp) writes all labels of the search in one coalesced pass
+            while (mine) {
+                const int b = __builtin_ctz(mine);
+                mine &= mine - 1;
+                d_labels[v0 + b] = label;
+            }
         }
         if (quad == 0 && in_range) {
             d_frontier_out[my_word] = d_merge ? (mask | d_merge[my_word]) : mask;  // (d_merge: this level's head-pass finds)
@@ -327,8 +334,11 @@ __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> 
     return p_found;
 }
 
+#ifndef GRX_BU_MIN_WAVES
+#define GRX_BU_MIN_WAVES 1
+#endif
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
-__global__ __launch_bounds__(THREADS) void BottomUpKernel(
+__global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpKernel(
     BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
     Lookup in_frontier)
 {
@@ -439,11 +449,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane);
                 const bool late = active && p_found >= 0;
                 if (late) {
-#ifndef GRX_EXP_NO_LABELS
-    #ifndef GRX_EXP_NO_LABELS
-                slice.d_labels[v] = new_label;
-#endif
-#endif
+                    if (!slice.defer_labels) slice.d_labels[v] = new_label;
                     if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = p_found;
                     found_count += 1;
                 }
@@ -460,11 +466,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpKernel(
                 const bool found = parent[j] >= 0;
                 if (found) {
                     const VertexId v = static_cast<VertexId>((step * STEP_WORDS + j) * 64 + lane);
-#ifndef GRX_EXP_NO_LABELS
-    #ifndef GRX_EXP_NO_LABELS
-                slice.d_labels[v] = new_label;
-#endif
-#endif
+                    if (!slice.defer_labels) slice.d_labels[v] = new_label;
                     if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent[j];
                     found_count += 1;
                 }
@@ -513,8 +515,11 @@ __device__ __forceinline__ int NthSetBit(unsigned long long x, int r)  // positi
     return pos;
 }
 
+#ifndef GRX_BUS_MIN_WAVES
+#define GRX_BUS_MIN_WAVES 1
+#endif
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup, bool EMIT_QUEUE>
-__global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
+__global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKernel(
     BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
     Lookup in_frontier)
 {
@@ -608,9 +613,7 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
                 if (more && late >= 0) parent = late;
             }
             if (parent >= 0) {
-#ifndef GRX_EXP_NO_LABELS
-                slice.d_labels[v] = new_label;
-#endif
+                if (!slice.defer_labels) slice.d_labels[v] = new_label;
                 if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
                 atomicOr(&s_found[wave][2 * j + (bit >> 5)], 1u << (bit & 31));
             }
@@ -658,6 +661,12 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
 }
 
 // ---- bitmap -> frontier queue (vertex, row start, degree prefix) through the FrontierWriter ----
+// Every workgroup owns a contiguous share of the bitmap.  It first counts the share's set bits (all word loads in flight
+// together, one reduction): an empty share ends there, and a share that fits the staging buffer -- every conversion back to
+// top-down, whose frontier is a few thousand vertices at most -- is appended wave by wave with NO workgroup barrier per
+// step and flushed once.  The conversion of a near-empty 2 MiB bitmap went 16 us -> the cost of reading it; only a share
+// with more set bits than the buffer holds (the queue of a binned level: millions of vertices) takes the stepwise path
+// with intermediate flushes.
 template <int THREADS, typename VertexId, typename SizeT>
 __global__ __launch_bounds__(THREADS) void BitmapToQueueKernel(const unsigned *d_bitmap, SizeT nodes,
                                                                util::Frontier<VertexId, SizeT> out,
@@ -665,20 +674,58 @@ __global__ __launch_bounds__(THREADS) void BitmapToQueueKernel(const unsigned *d
                                                                const SizeT *d_row_offsets)
 {
     constexpr int CAPACITY = 16 * THREADS;
+    constexpr int WAVES = THREADS / util::kWaveSize;
     typedef FrontierWriter<THREADS, CAPACITY, VertexId, SizeT> Writer;
     __shared__ typename Writer::Storage s_writer;
-    Writer::Init(s_writer);
-    __syncthreads();
+    __shared__ unsigned s_pop[WAVES];
 
     const long long words = (static_cast<long long>(nodes) + 31) / 32;
-    const long long chunk = THREADS;  // words per workgroup step: up to 32*THREADS appends
-    for (long long base = static_cast<long long>(blockIdx.x) * chunk; base < words; base += static_cast<long long>(gridDim.x) * chunk) {
+    const long long per_wg = ((words + gridDim.x - 1) / gridDim.x + THREADS - 1) / THREADS * THREADS;  // whole steps
+    const long long w_begin = static_cast<long long>(blockIdx.x) * per_wg;
+    const long long w_end = (w_begin + per_wg < words) ? w_begin + per_wg : words;
+    if (w_begin >= w_end) return;  // (workgroup-uniform)
+
+    unsigned pop = 0;
+    for (long long w = w_begin + threadIdx.x; w < w_end; w += THREADS) pop += static_cast<unsigned>(__popc(d_bitmap[w]));
+    pop = util::WaveSum(pop);
+    if (util::LaneId() == 0) s_pop[threadIdx.x / util::kWaveSize] = pop;
+    Writer::Init(s_writer);
+    __syncthreads();
+    unsigned share = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) share += s_pop[w];
+    if (share == 0) return;  // (workgroup-uniform)
+
+    auto put = [&](long long wi, unsigned bits, int pos) {
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const long long v = wi * 32 + b;
+            s_writer.buf[pos++] = static_cast<VertexId>(v < nodes ? v : nodes - 1);  // (tail bits are never set)
+        }
+    };
+
+    if (share <= static_cast<unsigned>(CAPACITY)) {
+        for (long long base = w_begin; base < w_end; base += THREADS) {  // (uniform trip count: Reserve is wave-collective)
+            const long long wi = base + threadIdx.x;
+            const unsigned word = (wi < w_end) ? d_bitmap[wi] : 0u;
+            const int pos = Writer::Reserve(s_writer, __popc(word));
+            put(wi, word, pos);
+        }
+        __syncthreads();
+        const int staged = Writer::Count(s_writer);
+        __syncthreads();
+        Writer::template Flush<true>(s_writer, staged, out, d_tail_out, d_overflow, d_row_offsets);
+        return;
+    }
+
+    for (long long base = w_begin; base < w_end; base += THREADS) {
         const int pending = Writer::Count(s_writer);
         __syncthreads();
         // a step can append at most 32 * THREADS entries: flush first if that might not fit.  To keep the
         // staging buffer small the step is split in four 8-bit slices of every word.
         const long long wi = base + threadIdx.x;
-        const unsigned word = (wi < words) ? d_bitmap[wi] : 0u;
+        const unsigned word = (wi < w_end) ? d_bitmap[wi] : 0u;
         int carried = pending;
 #pragma unroll
         for (int slice8 = 0; slice8 < 4; ++slice8) {
@@ -686,16 +733,9 @@ __global__ __launch_bounds__(THREADS) void BitmapToQueueKernel(const unsigned *d
                 Writer::template Flush<true>(s_writer, carried, out, d_tail_out, d_overflow, d_row_offsets);
                 carried = 0;
             }
-            unsigned bits = (word >> (8 * slice8)) & 0xFFu;
-            const int mine = __popc(bits);
-            int pos = Writer::Reserve(s_writer, mine);
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                bits &= bits - 1;
-                const long long v = wi * 32 + 8 * slice8 + b;
-                if (v < nodes) s_writer.buf[pos++] = static_cast<VertexId>(v);
-                else s_writer.buf[pos++] = static_cast<VertexId>(nodes - 1);  // unreachable: tail bits are never set
-            }
+            const unsigned bits = word & (0xFFu << (8 * slice8));
+            const int pos = Writer::Reserve(s_writer, __popc(bits));
+            put(wi, bits, pos);
             __syncthreads();
             carried = Writer::Count(s_writer);
             __syncthreads();

@@ -39,6 +39,8 @@ struct BfsRunner {
     virtual void SetTwcLimit(int limit) = 0;
     virtual void SetCooperativeLaunch(bool on) = 0;
     virtual void SetBinnedMinEdges(long long min_edges) = 0;
+    virtual void SetLabelDeferral(int enabled, int mask_limit) = 0;
+    virtual int SetOption(const char *name, double value) = 0;
     virtual void SetHeadPass(int min_edges, int max_edges) = 0;
     virtual hipError_t Reset(int src, double queue_sizing) = 0;
     virtual hipError_t Enact(int src, int max_grid_size, int traversal_mode, float *ms) = 0;
@@ -129,6 +131,21 @@ struct BfsRunnerT : BfsRunner {
     void SetTwcLimit(int limit) override { problem.twc_edge_limit = limit; }
     void SetCooperativeLaunch(bool on) override { problem.cooperative_launch = on; }
     void SetBinnedMinEdges(long long min_edges) override { problem.binned_min_edges = min_edges; }
+    int SetOption(const char *name, double value) override
+    {
+        const std::string key(name ? name : "");
+        if (key == "emit_queue_factor") problem.emit_queue_factor = static_cast<float>(value);
+        else if (key == "sparse_sweep_div") problem.sparse_sweep_div = static_cast<int>(value);
+        else if (key == "speculative_emit") problem.speculative_emit = value != 0.0;
+        else if (key == "chain_sweeps") problem.chain_sweeps = static_cast<int>(value);
+        else return 1;
+        return 0;
+    }
+    void SetLabelDeferral(int enabled, int mask_limit) override
+    {
+        if (enabled >= 0) problem.defer_labels = enabled != 0;
+        if (mask_limit > 0) problem.level_mask_limit = mask_limit;
+    }
     void SetHeadPass(int min_edges, int max_edges) override
     {
         problem.head_pass_min_edges = min_edges;
@@ -282,6 +299,19 @@ int grx_bfs_set_head_pass(grx_bfs *p, int min_edges, int max_edges)
 {
     if (!p || !p->runner || min_edges < -1 || max_edges < -1) return 1;
     p->runner->SetHeadPass(min_edges, max_edges);
+    return 0;
+}
+
+int grx_bfs_set_option(grx_bfs *p, const char *name, double value)
+{
+    if (!p || !p->runner) return -1;
+    return p->runner->SetOption(name, value);
+}
+
+int grx_bfs_set_label_deferral(grx_bfs *p, int enabled, int mask_limit)
+{
+    if (!p) return -1;
+    p->runner->SetLabelDeferral(enabled, mask_limit);
     return 0;
 }
 

@@ -56,6 +56,7 @@ struct PbfsProblem {
         unsigned *d_visited_mask;   // local ids
         unsigned *d_sent_mask;      // GLOBAL ids: destinations this rank has already forwarded
         int iteration;
+        int defer_labels = 0;       // (BFSProblem's deferred labelling is not used here: the sweeps write labels themselves)
         int *d_pred_global;         // mark_pred: GLOBAL ids -> the local source that forwarded it (as a global id), else nullptr
         const int *d_recv_preds;    // mark_pred: parents that arrived with the ids being filtered, else nullptr
         int parts, rank;
@@ -152,6 +153,11 @@ __global__ void ScatterByOwnerKernel(const int *d_ids, int n, int parts, unsigne
 
 // ---- the same two bucketing steps for the in-library loop: the candidate count stays on the device (low word of a packed
 //      tail), the scatter computes the segment offsets itself, parents travel next to the ids ----
+// layout of Pbfs::d_small (words): [0] error word, [1, 65) counts to send, [65, 129) cursors, [192, ...) gathered matrices
+constexpr int kSmallCounts = 1, kSmallCursors = 65, kSmallGathered = 192, kSmallMaxParts = 64;
+constexpr int kSmallWords = kSmallGathered + (kSmallMaxParts + 1) * kSmallMaxParts;   // device words
+constexpr int kMailWords = (kSmallMaxParts + 1) * kSmallMaxParts;                     // pinned mailbox words (+ sequence word behind)
+
 __global__ void CountOwnersDeviceKernel(const int *d_ids, const unsigned long long *d_n, int parts, unsigned *d_counts)
 {
     __shared__ unsigned s_count[64];
@@ -253,10 +259,12 @@ __global__ void PbfsResetKernel(int src, int parts, int rank, const int *d_row_o
 }
 
 // start of a top-down level: the two tail slots and the owner histogram (counts, cursors) back to zero -- one launch
-__global__ void PbfsArmLevelKernel(unsigned long long *d_tail, unsigned *d_small)
+// d_small[0] = this rank's error word for the level's count all-gather (the queue-overflow flag as earlier levels left it):
+// every rank sees every rank's word in the gathered matrix, so all of them leave the level loop at the same level
+__global__ void PbfsArmLevelKernel(unsigned long long *d_tail, unsigned *d_small, const int *d_overflow)
 {
     if (threadIdx.x < 2) d_tail[threadIdx.x] = 0ull;
-    if (threadIdx.x < 128) d_small[threadIdx.x] = 0u;
+    if (threadIdx.x < kSmallGathered) d_small[threadIdx.x] = (threadIdx.x == 0 && *d_overflow != 0) ? 1u : 0u;
 }
 
 // sum of the wide tail lines (the bottom-up sweep's per-workgroup find counts) -> one word, lines cleared
@@ -438,8 +446,8 @@ struct Pbfs : app::EnactorBase {
     int *d_recv = nullptr;               // received local ids, then (mark_pred) received parents behind them
     int recv_capacity = 0;
     int *d_send_preds = nullptr;
-    unsigned *d_small = nullptr;         // [0, 64): counts to send; [64, 128): cursors; [128, 128 + 64 * 64): gathered matrices
-    unsigned *h_small = nullptr;         // pinned + mapped mirror of the gathered part; word [64 * 64] onwards: the mail sequence
+    unsigned *d_small = nullptr;         // kSmall* layout: error word, counts to send, cursors, gathered matrices
+    unsigned *h_small = nullptr;         // pinned + mapped mirror of the gathered part; word [kMailWords] onwards: the mail sequence
     unsigned long long mail_seq = 0;
     unsigned *d_visited_before = nullptr;  // local visited bitmap as it was before the last top-down level
     unsigned *d_gathered = nullptr;      // parts x (bitmap words + 2)
@@ -786,9 +794,10 @@ struct Pbfs : app::EnactorBase {
         hipError_t retval = hipSuccess;
         if (!transport) return hipErrorNotInitialized;
         if (!d_small) {
-            GR_CHECK(hipMalloc(&d_small, sizeof(unsigned) * (128 + 64 * 64)), "Pbfs hipMalloc failed");
-            GR_CHECK(hipHostMalloc(&h_small, sizeof(unsigned) * (64 * 64 + 4), hipHostMallocMapped), "Pbfs hipHostMalloc failed");
-            std::memset(h_small, 0, sizeof(unsigned) * (64 * 64 + 4));
+            if (parts > kSmallMaxParts) return util::GRError(hipErrorInvalidValue, "Pbfs: more than 64 ranks", __FILE__, __LINE__);
+            GR_CHECK(hipMalloc(&d_small, sizeof(unsigned) * kSmallWords), "Pbfs hipMalloc failed");
+            GR_CHECK(hipHostMalloc(&h_small, sizeof(unsigned) * (kMailWords + 4), hipHostMallocMapped), "Pbfs hipHostMalloc failed");
+            std::memset(h_small, 0, sizeof(unsigned) * (kMailWords + 4));
             GR_CHECK(hipMalloc(&d_visited_before, sizeof(unsigned) * (MaskWords(n_local) + 2)), "Pbfs hipMalloc failed");
             GR_CHECK(hipMalloc(&d_gathered, sizeof(unsigned) * static_cast<size_t>(parts) * (MaskWords(n_local_max) + 2)), "Pbfs hipMalloc failed");
             // a rank forwards every vertex at most once per search, so at most parts * (my vertices) ids arrive per search
@@ -805,8 +814,8 @@ struct Pbfs : app::EnactorBase {
         if (m_global < 0) {  // sum of the local edge counts (two 31-bit halves per rank through the word all-gather)
             const unsigned halves[2] = {static_cast<unsigned>(m_local) & 0xFFFFu, static_cast<unsigned>(m_local) >> 16};
             GR_CHECK(hipMemcpyAsync(d_small, halves, sizeof(halves), hipMemcpyHostToDevice, stream), "Pbfs copy failed");
-            if (transport->AllGather(d_small, d_small + 128, 2, stream)) return hipErrorUnknown;
-            GR_CHECK(hipMemcpyAsync(h_small, d_small + 128, sizeof(unsigned) * 2 * parts, hipMemcpyDeviceToHost, stream), "Pbfs copy failed");
+            if (transport->AllGather(d_small, d_small + kSmallGathered, 2, stream)) return hipErrorUnknown;
+            GR_CHECK(hipMemcpyAsync(h_small, d_small + kSmallGathered, sizeof(unsigned) * 2 * parts, hipMemcpyDeviceToHost, stream), "Pbfs copy failed");
             GR_CHECK(hipStreamSynchronize(stream), "Pbfs sync failed");
             m_global = 0;
             for (int p = 0; p < parts; ++p) m_global += static_cast<long long>(h_small[2 * p]) + (static_cast<long long>(h_small[2 * p + 1]) << 16);
@@ -818,7 +827,7 @@ struct Pbfs : app::EnactorBase {
     hipError_t Mail(const unsigned *d_src, int count, int stride)
     {
         hipError_t retval = hipSuccess;
-        unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(h_small + 64 * 64);
+        unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(h_small + kMailWords);
         ++mail_seq;
         hipLaunchKernelGGL(MailKernel, dim3(1), dim3(64), 0, stream, d_src, count, stride, h_small, h_seq, mail_seq);
         GR_CHECK(hipGetLastError(), "MailKernel launch failed");
@@ -841,8 +850,8 @@ struct Pbfs : app::EnactorBase {
                           unsigned &my_edges)
     {
         hipError_t retval = hipSuccess;
-        if (transport->AllGather(reinterpret_cast<const unsigned *>(d_tail_word), d_small + 128, 2, stream)) return hipErrorUnknown;
-        if ((retval = Mail(d_small + 128, 2 * parts, 1))) return retval;
+        if (transport->AllGather(reinterpret_cast<const unsigned *>(d_tail_word), d_small + kSmallGathered, 2, stream)) return hipErrorUnknown;
+        if ((retval = Mail(d_small + kSmallGathered, 2 * parts, 1))) return retval;
         glen = 0; gedges = 0;
         for (int p = 0; p < parts; ++p) {  // PackTail: low word = vertices, high word = edges
             glen += h_small[2 * p];
@@ -917,7 +926,7 @@ struct Pbfs : app::EnactorBase {
             unexplored -= static_cast<long long>(gedges);
             GR_CHECK(hipMemcpyAsync(d_visited_before, ds.d_visited_mask, sizeof(unsigned) * (wpr_local + 2), hipMemcpyDeviceToDevice, stream),
                      "Pbfs visited snapshot failed");
-            hipLaunchKernelGGL(PbfsArmLevelKernel, dim3(1), dim3(128), 0, stream, work_progress.d_tail, d_small);
+            hipLaunchKernelGGL(PbfsArmLevelKernel, dim3(1), dim3(256), 0, stream, work_progress.d_tail, d_small, work_progress.d_overflow);
             GR_CHECK(hipGetLastError(), "PbfsArmLevelKernel launch failed");
             if (frontier_len > 0) {
                 oprtr::advance::AdvanceArgs<int, int> args;
@@ -937,25 +946,38 @@ struct Pbfs : app::EnactorBase {
                 if ((retval = oprtr::advance::LaunchKernel<Policy, PbfsProblem, SendFunctor, false>(args, ds, 0, stream))) return retval;
                 // (the candidate count stays on the device: the bucketing kernels read it there)
                 const int grid = cu_count * 4;
-                hipLaunchKernelGGL(CountOwnersDeviceKernel, dim3(grid), dim3(256), 0, stream, d_candidates, work_progress.d_tail + 0, parts, d_small);
+                hipLaunchKernelGGL(CountOwnersDeviceKernel, dim3(grid), dim3(256), 0, stream, d_candidates, work_progress.d_tail + 0, parts, d_small + kSmallCounts);
                 GR_CHECK(hipGetLastError(), "CountOwnersDeviceKernel launch failed");
                 hipLaunchKernelGGL(ScatterByOwnerDeviceKernel, dim3(grid), dim3(256), 0, stream, d_candidates, work_progress.d_tail + 0, parts,
-                                   d_small, d_small + 64, d_send, mark_pred ? ds.d_pred_global : nullptr, mark_pred ? d_send_preds : nullptr);
+                                   d_small + kSmallCounts, d_small + kSmallCursors, d_send, mark_pred ? ds.d_pred_global : nullptr, mark_pred ? d_send_preds : nullptr);
                 GR_CHECK(hipGetLastError(), "ScatterByOwnerDeviceKernel launch failed");
             }
-            // P x P count matrix: row p = what rank p sends to everybody
-            if (transport->AllGather(d_small, d_small + 128, static_cast<size_t>(parts), stream)) return hipErrorUnknown;
-            if ((retval = Mail(d_small + 128, parts * parts, 1))) return retval;
+            // P x (1 + P) matrix: row p = rank p's error word, then what rank p sends to everybody
+            const int row = parts + 1;
+            if (transport->AllGather(d_small, d_small + kSmallGathered, static_cast<size_t>(row), stream)) return hipErrorUnknown;
+            if ((retval = Mail(d_small + kSmallGathered, parts * row, 1))) return retval;
             size_t send_total = 0, recv_total = 0;
             for (int p = 0; p < parts; ++p) {
-                sc[p] = h_small[rank * parts + p];
+                sc[p] = h_small[rank * row + 1 + p];
                 so[p] = send_total;
                 send_total += sc[p];
-                rc[p] = h_small[p * parts + rank];
+                rc[p] = h_small[p * row + 1 + rank];
                 ro[p] = recv_total;
                 recv_total += rc[p];
             }
-            if (recv_total > static_cast<size_t>(recv_capacity)) return util::GRError(hipErrorInvalidConfiguration, "Pbfs receive buffer overflow", __FILE__, __LINE__);
+            // Errors every rank can read off the same matrix, so that ALL ranks leave here together and nobody is left waiting
+            // in the next collective: a rank whose queues overflowed on an earlier level (its error word), or a rank that would
+            // receive more ids than its buffer holds (column sums; the capacity is the same on every rank).
+            for (int p = 0; p < parts; ++p) {
+                size_t into_p = 0;
+                for (int q = 0; q < parts; ++q) into_p += h_small[q * row + 1 + p];
+                if (h_small[p * row] != 0)
+                    return util::GRError(hipErrorInvalidConfiguration, p == rank ? "Frontier queue overflow. Please increase queue-sizing factor."
+                                                                                 : "Pbfs: a peer rank reported a frontier queue overflow", __FILE__, __LINE__);
+                if (into_p > static_cast<size_t>(recv_capacity))
+                    return util::GRError(hipErrorInvalidConfiguration, p == rank ? "Pbfs receive buffer overflow" : "Pbfs: a peer rank's receive buffer would overflow",
+                                         __FILE__, __LINE__);
+            }
             if (transport->AllToAllV(d_send, sc.data(), so.data(), d_recv, rc.data(), ro.data(), stream)) return hipErrorUnknown;
             if (mark_pred && transport->AllToAllV(d_send_preds, sc.data(), so.data(), d_recv + recv_capacity, rc.data(), ro.data(), stream))
                 return hipErrorUnknown;
@@ -1072,6 +1094,11 @@ int grx_pbfs_preds(grx_pbfs *p, int **d_preds)
     if (!p || !d_preds) return -1;
     *d_preds = p->impl.ds.d_preds;
     return 0;
+}
+
+int grx_rccl_load(void)
+{
+    return RcclApi::Get().Load() ? 0 : -2;  // dlopen + dlsym only: no communicator, nothing collective
 }
 
 int grx_rccl_unique_id(char id[128])

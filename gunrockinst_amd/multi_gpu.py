@@ -319,11 +319,16 @@ class LibraryBfs:
         self._h = engine._h
         if transport in ("rccl", "rccl-or-callbacks"):
             # every rank must end up on the same transport: the outcome of each step is agreed on before the next one
-            buf = C.create_string_buffer(128)
-            rc = self.lib.grx_rccl_unique_id(buf) if comm.rank == 0 else 0
-            box = [bytes(buf.raw), int(rc)]
-            dist.broadcast_object_list(box, src=0, group=comm.group)
-            rc = box[1]
+            # step 1 is local (dlopen + dlsym): if ANY rank cannot load RCCL, no rank may enter ncclCommInitRank -- that call is
+            # collective, and the ranks that did load would wait in it forever for the ones that already gave up
+            (rc,) = comm.all_reduce_max([abs(int(self.lib.grx_rccl_load()))])
+            box = [b"", int(rc)]
+            if rc == 0:
+                buf = C.create_string_buffer(128)
+                rc = self.lib.grx_rccl_unique_id(buf) if comm.rank == 0 else 0
+                box = [bytes(buf.raw), int(rc)]
+                dist.broadcast_object_list(box, src=0, group=comm.group)
+                rc = box[1]
             if rc == 0:
                 rc = self.lib.grx_pbfs_comm_init_rccl(self._h, box[0])
                 (rc,) = comm.all_reduce_max([abs(int(rc))])

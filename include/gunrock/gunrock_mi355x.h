@@ -123,6 +123,16 @@ int grx_bfs_set_cooperative_launch(grx_bfs *p, int on);
  * (0 = never; default 2^23).  This replaces the per-edge atomicCAS of the reference's functor (bfs_functor.cuh:56-58) on the
  * levels where it dominates.  Results do not depend on it. */
 int grx_bfs_set_binned_min_edges(grx_bfs *p, long long min_edges);
+/* Deferred labels of a direction-optimizing search (DESIGN.md 3.3 i): sweeps that find vertices in vertex order keep their
+ * output bitmap and ONE pass at the end of Enact writes every label.  enabled: 1 / 0, -1 = leave; mask_limit: frontier
+ * bitmaps a search may hold before it flushes the kept ones into the labels (4..12, 0 = leave; tests shrink it).  Takes
+ * effect at the next grx_bfs_reset.  Labels are identical either way. */
+int grx_bfs_set_label_deferral(grx_bfs *p, int enabled, int mask_limit);
+/* Enactor tuning by name (returns 1 for an unknown name): "emit_queue_factor" (a compacting bottom-up sweep also writes its
+ * finds as the next top-down queue when its input frontier is within this factor of the switch-back threshold),
+ * "sparse_sweep_div", "speculative_emit" (1/0: the label pass is queued behind the closing top-down launch without waiting
+ * for its read-back), "chain_sweeps" (bottom-up sweeps queued per host round trip).  Results never depend on them. */
+int grx_bfs_set_option(grx_bfs *p, const char *name, double value);
 /* Direction-optimizing only: a level that would run count-only or bottom-up and has between `min_edges` and `max_edges`
  * frontier edges starts with a bottom-up pass that probes only the adjacency heads (the highest-degree in-neighbours); the
  * count-only top-down advance then handles what is left.  -1 = automatic bounds (edges/30 .. edges/7.8), min 0 = never,
@@ -268,7 +278,10 @@ int grx_pbfs_preds(grx_pbfs *p, int **d_preds);
  *   bottom-up level: ONE ncclAllGather of the per-rank frontier bitmaps whose trailing word carries each rank's frontier
  *                    size -> local sweep; the search stays bottom-up to the end once Beamer's edge rule fires.
  * grx_rccl_unique_id: rank 0 creates the 128-byte ncclUniqueId, the caller distributes it (any channel) and every rank calls
- * grx_pbfs_comm_init_rccl after grx_pbfs_init_device.  RCCL is dlopen'ed on first use (librccl.so.1). */
+ * grx_pbfs_comm_init_rccl after grx_pbfs_init_device.  RCCL is dlopen'ed on first use (librccl.so.1).
+ * grx_rccl_load only loads the library (0 = every symbol resolved): ranks agree on its outcome BEFORE any of them enters
+ * ncclCommInitRank, which is collective and would block the ranks that did load while the others have already given up. */
+int grx_rccl_load(void);
 int grx_rccl_unique_id(char id[128]);
 int grx_pbfs_comm_init_rccl(grx_pbfs *p, const char id[128]);
 /* the same loop with the three exchanges performed by the caller, synchronously, on device pointers (tests run several

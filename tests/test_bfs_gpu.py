@@ -324,6 +324,59 @@ def test_head_pass_then_count_only_level_parity(min_edges, lite_factor, tail_lim
             p.close()
 
 
+@pytest.mark.parametrize("deferral,mask_limit", [(1, 0), (1, 4), (0, 0)])
+@pytest.mark.parametrize("beta,lite_factor,min_edges", [(0.0, -1.0, -1), (1e12, 1e9, 1), (1e12, 0.0, 0)])
+def test_deferred_labels_equal_labels_at_discovery(deferral, mask_limit, beta, lite_factor, min_edges):
+    # Direction-optimizing searches keep the bitmaps of their vertex-ordered levels and write every label in ONE pass at the end
+    # of Enact (Reset fills nothing).  Same labels with the deferral on, off, and with a pool of only 4 bitmaps, which forces the
+    # kept levels to be flushed in the middle of a search (beta huge: the search never returns to top-down, so every level after the
+    # switch is a bitmap level).  The problem is reused across sources and modes, so labels of the PREVIOUS search lie in the
+    # array when the next one starts -- the emit pass must overwrite every one of them, also after a top-down-only Enact.
+    for scale, ef in [(10, 8), (16, 8), (18, 16)]:
+        g = o.rmat_seeded(scale, ef << scale)
+        deg = np.diff(g.row_offsets)
+        srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist() + [int(np.nonzero(deg == 0)[0][0])]
+        for mark_pred in (False, True):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph(beta=beta)
+            p.set_tuning(lite_factor=lite_factor)
+            p.set_head_pass(min_edges, 0 if min_edges >= 0 else -1)
+            p.set_label_deferral(deferral, mask_limit)
+            for src in srcs:
+                for mode in (2, 0, 2):
+                    p.reset(int(src))
+                    p.enact(int(src), traversal_mode=mode)
+                    labels, preds = p.extract()
+                    _check(g, int(src), labels, preds, p.stats())
+            # Reset without Enact: Extract must still hand back a fully defined array (source 0, everything else -1)
+            p.reset(int(srcs[0]))
+            labels, _ = p.extract()
+            want = np.full(g.nodes, -1, dtype=np.int32)
+            want[int(srcs[0])] = 0
+            assert np.array_equal(labels, want)
+            p.close()
+
+
+def test_deferred_labels_on_a_long_bottom_up_run():
+    # a path-like graph searched bottom-up only (alpha and beta huge): hundreds of bitmap levels through a pool of 4..12 bitmaps
+    n = 3000
+    rows = np.arange(n - 1, dtype=np.int32)
+    g = ga.HostGraph.from_coo(n, np.concatenate([rows, rows + 1]), np.concatenate([rows + 1, rows]))
+    og = o.Csr(g.nodes, g.row_offsets, g.col_indices)
+    for mask_limit in (4, 12):
+        p = ga.BfsProblem(True, True).init(g.nodes, g.row_offsets, g.col_indices)
+        p.set_inverse_graph(alpha=1e12, beta=1e12)
+        p.set_tuning(tail_edge_limit=0)
+        p.set_label_deferral(1, mask_limit)
+        for src in (0, n // 2):
+            p.reset(src)
+            p.enact(src, traversal_mode=2)
+            labels, preds = p.extract()
+            assert np.array_equal(labels, o.bfs(og, src)[0])
+            assert o.check_bfs_preds(og, src, labels, preds) == 0
+        p.close()
+
+
 @pytest.mark.parametrize("min_edges,lite_factor,beta", [(1, 1e9, 0.0), (1, 8.0, 2.0), (0, 1e9, 50.0), (-1, -1.0, 0.0)])
 def test_directed_graph_new_level_kinds(min_edges, lite_factor, beta):
     # directed R-MAT with an explicit in-neighbour CSR: heads ranked by IN-degree, compacted head indices, the heads-then-rest
