@@ -237,7 +237,7 @@ class BFSEnactor : public EnactorBase {
             // nearly finished search: few vertices can still be unvisited -> the compacting sweep (bottom_up.hpp)
             const long long open_estimate = problem->with_in_edges - enactor_stats.total_queued;
             if (problem->sparse_sweep_div > 0 && open_estimate * problem->sparse_sweep_div <= static_cast<long long>(problem->nodes)) {
-                const long long chunks = ((static_cast<long long>(problem->nodes) + 63) / 64 + 15) / 16;
+                const long long chunks = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kSparseChunkWords - 1) / oprtr::advance::kSparseChunkWords;
                 long long sgrid = (chunks + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
                 if (sgrid < 1) sgrid = 1;
                 typedef oprtr::advance::BitmapLookup<VertexId> L;
@@ -276,6 +276,115 @@ class BFSEnactor : public EnactorBase {
                                dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
             return util::GRError("BottomUpKernel launch failed", __FILE__, __LINE__);
         };
+        // ---- a CHAIN of bottom-up sweeps behind one host round trip (bottom_up.hpp BottomUpAutoKernel) ----
+        // The frontier is d_frontier_mask[cur_mask]; its size is `first_in`, or -- when the host has not read it back (the chain
+        // follows a count-only level directly) -- the sum of wide set 0.  Every queued sweep decides on the device whether it runs
+        // dense, compacting (with or without an emitted queue) or not at all; afterwards the host replays the same rules on the
+        // published sums to learn how many ran, which bitmaps they filled and what the next frontier is.
+        const int chain_len = (dobfs && problem->chain_sweeps > 0)
+            ? (problem->chain_sweeps < oprtr::advance::kChainMax ? problem->chain_sweeps : oprtr::advance::kChainMax) : 0;
+        work_progress.publish_sets = chain_len > 0 ? chain_len + 1 : 1;
+        oprtr::advance::SweepRule sweep_rule;
+        sweep_rule.with_in_edges = problem->with_in_edges;
+        sweep_rule.nodes = problem->nodes;
+        sweep_rule.beta = problem->beta;
+        sweep_rule.emit_factor = problem->emit_queue_factor;
+        sweep_rule.sparse_div = problem->sparse_sweep_div;
+        auto run_sweep_chain = [&](long long first_in) -> hipError_t {
+            typedef oprtr::advance::BitmapLookup<VertexId> L;
+            hipError_t rc = hipSuccess;
+            const long long it0 = iteration;
+            const long long base_total = enactor_stats.total_queued;
+            int masks[oprtr::advance::kChainMax + 1];
+            masks[0] = cur_mask;
+            int queued = 0;
+            const long long bu_steps = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kBottomUpStepWords - 1) / oprtr::advance::kBottomUpStepWords;
+            long long grid = (bu_steps + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+            const long long cap = max_grid_size > 0 ? max_grid_size
+                : util::ResidentGrid(oprtr::advance::BottomUpAutoKernel<BU_THREADS, 8, 32, BFSProblem, L>, BU_THREADS);
+            if (grid > cap) grid = cap;
+            if (grid < 1) grid = 1;
+            const long long chunks = ((static_cast<long long>(problem->nodes) + 63) / 64 + oprtr::advance::kSparseChunkWords - 1) / oprtr::advance::kSparseChunkWords;
+            long long sparse_grid = (chunks + (BU_THREADS / 64) - 1) / (BU_THREADS / 64);
+            if (sparse_grid < 1) sparse_grid = 1;
+            long long emit_grid = sparse_grid < cu_count * 4 ? sparse_grid : cu_count * 4;  // (each workgroup ends with an atomic on one word)
+            for (int k = 1; k <= chain_len; ++k) {
+                bool got = false;
+                if ((rc = problem->TryAcquireMask(stream, masks[k], masks, k, got))) return rc;
+                if (!got) break;  // the pool is full of bitmaps this chain still reads: a shorter chain
+                oprtr::advance::BottomUpArgs<VertexId, SizeT> bargs;
+                bargs.nodes = problem->nodes;
+                bargs.d_inv_row_offsets = ds->d_inv_row_offsets;
+                bargs.d_inv_column_indices = ds->d_inv_column_indices;
+                bargs.d_inv_heads = ds->d_inv_heads;
+                L lookup{ds->d_frontier_mask[masks[k - 1]]};
+                bargs.d_frontier_out = reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[masks[k]]);
+                bargs.d_visited = reinterpret_cast<unsigned long long *>(ds->d_visited_mask);
+                const long long level = it0 + k - 1;  // the BSP iteration this sweep is
+                bargs.d_tail_out = work_progress.d_tail + ((level + 1) & 3);
+                bargs.d_tail_clear = work_progress.d_tail + ((level + 2) & 3);
+                bargs.d_wide = work_progress.d_wide + static_cast<size_t>(k) * util::WorkProgress::kWideSetWords;
+                bargs.head_skip = 0;
+                bargs.heads_only = 0;
+                bargs.d_never = reinterpret_cast<const unsigned long long *>(ds->d_never_mask);
+                bargs.d_head_base = ds->d_head_base;
+                bargs.d_duty = INSTRUMENT ? DutySlot() : nullptr;
+                bargs.queue_out = gs->frontier_queues[selector];
+                bargs.d_fwd_row_offsets = gs->d_row_offsets;
+                bargs.d_queue_tail = work_progress.d_tail + ((level + 1) & 3);
+                bargs.d_queue_invalid = reinterpret_cast<int *>(work_progress.AuxTail());
+                bargs.d_overflow = work_progress.d_overflow;
+                oprtr::advance::SweepChain chain;
+                chain.d_sets = work_progress.d_wide;
+                chain.base_total = base_total;
+                chain.first_in = first_in;
+                chain.rule = sweep_rule;
+                chain.index = k;
+                chain.first_may_switch = 0;  // (the host has just applied the switch-back rule to the first frontier, or has just turned bottom-up)
+                chain.d_log = work_progress.d_chain_log;
+                typename BFSProblem::DataSlice level_slice = *ds;
+                level_slice.iteration = static_cast<VertexId>(level);
+                hipLaunchKernelGGL((oprtr::advance::BottomUpAutoKernel<BU_THREADS, 8, 32, BFSProblem, L>), dim3(static_cast<unsigned>(grid)),
+                                   dim3(BU_THREADS), 0, stream, bargs, level_slice, lookup, chain, static_cast<unsigned>(sparse_grid),
+                                   static_cast<unsigned>(emit_grid));
+                if ((rc = util::GRError("BottomUpAutoKernel launch failed", __FILE__, __LINE__))) return rc;
+                queued = k;
+            }
+            if (queued == 0) return util::GRError(hipErrorInvalidValue, "BFSEnactor: no frontier bitmap for a bottom-up sweep", __FILE__, __LINE__);
+            if (INSTRUMENT && (rc = InstrumentEnd(stream))) return rc;
+            if ((rc = work_progress.Sync(stream))) return rc;
+            // ---- replay (the same SweepRule on the same numbers) ----
+            long long total = base_total;
+            int ran = 0, last_action = oprtr::advance::kSweepStop;
+            long long next_in = 0;
+            for (int k = 1; k <= queued + 1; ++k) {
+                const long long in_k = (k == 1 && first_in >= 0) ? first_in
+                    : static_cast<long long>(util::TailCount(k == 1 ? work_progress.box->wide : work_progress.box->wide_set[k - 1]));
+                next_in = in_k;
+                if (k > queued) break;  // the frontier the last queued sweep produced: the host loop takes it from here
+                const int action = sweep_rule.Decide(in_k, total + in_k, k > 1);
+                if (action != work_progress.box->chain_log[k])
+                    return util::GRError(hipErrorUnknown, "BFSEnactor: host and device disagree about a chained sweep", __FILE__, __LINE__);
+                if (action <= oprtr::advance::kSweepSwitch) break;
+                total += in_k;
+                ran = k;
+                last_action = action;
+                if (deferring) problem->KeepMask(masks[k], static_cast<VertexId>(it0 + k));
+            }
+            enactor_stats.total_queued = total;
+            iteration = it0 + ran;
+            cur_mask = masks[ran];
+            queue_length = static_cast<unsigned>(next_in);
+            queue_edges = 0;
+            queue_emitted = ran > 0 && last_action == oprtr::advance::kSweepSparseEmit;
+            out_slot_clean = ran > 0 && !queue_emitted;  // (a sweep that emits nothing zeroes its queue-tail slot itself)
+            if (queue_emitted && work_progress.h_tail[util::WorkProgress::kAux] != 0) {  // a staging buffer overflowed: no usable queue
+                queue_emitted = false;
+                if ((rc = work_progress.ClearAux(stream))) return rc;
+            }
+            if (INSTRUMENT) InstrumentCollect(static_cast<long long>(first_in >= 0 ? first_in : 0), 0, 1);
+            return rc;
+        };
         // count-only top-down advance over the current queue: unvisited destinations get their d_fresh byte set
         auto launch_count_only = [&](oprtr::advance::AdvanceArgs<VertexId, SizeT> args) -> hipError_t {
             ds->lite = 1;
@@ -296,7 +405,7 @@ class BFSEnactor : public EnactorBase {
                                ds->d_fresh, static_cast<long long>(problem->nodes), reinterpret_cast<unsigned long long *>(ds->d_visited_mask),
                                d_before, reinterpret_cast<unsigned long long *>(ds->d_frontier_mask[out_mask]),
                                deferring ? static_cast<VertexId *>(nullptr) : ds->d_labels, static_cast<VertexId>(iteration + 1), work_progress.d_tail + ((iteration + 1) & 3), work_progress.d_wide,
-                               d_merge);
+                               d_merge, work_progress.d_tail + ((iteration + 2) & 3));
             if (deferring) problem->KeepMask(out_mask, static_cast<VertexId>(iteration + 1));
             return util::GRError("FreshToBitmapKernel launch failed", __FILE__, __LINE__);
         };
@@ -364,10 +473,21 @@ class BFSEnactor : public EnactorBase {
                                                 reinterpret_cast<const unsigned long long *>(ds->d_frontier_mask[heads_mask]), out_mask)))
                     break;
                 cur_mask = out_mask;
-                force_bottom_up = true;
                 snapshot_valid = false;
-                if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                 ++iteration;
+                if (chain_len > 0) {  // the bottom-up sweeps follow without a round trip: the level's size stays on the device
+                    if (INSTRUMENT) {
+                        if ((retval = InstrumentEnd(stream))) break;
+                        if ((retval = util::GRError(hipStreamSynchronize(stream), "BFSEnactor instrument sync failed", __FILE__, __LINE__))) break;
+                        InstrumentCollect(in_len, in_edges, 6);
+                        if ((retval = InstrumentBegin(stream))) break;
+                    }
+                    bottom_up = true;
+                    if ((retval = run_sweep_chain(-1))) break;
+                    continue;
+                }
+                force_bottom_up = true;
+                if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                 if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
                 if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 6);
                 continue;  // (selector unchanged: no queue was written)
@@ -446,6 +566,10 @@ class BFSEnactor : public EnactorBase {
                 if (iteration != before) continue;
                 if (INSTRUMENT && (retval = InstrumentBegin(stream))) break;
             }
+            if (bottom_up && chain_len > 0) {  // bottom-up levels: several sweeps behind one round trip
+                if ((retval = run_sweep_chain(static_cast<long long>(queue_length)))) break;
+                continue;
+            }
             enactor_stats.total_queued += queue_length;
             enactor_stats.total_edges_queued += queue_edges;
             unexplored_edges -= queue_edges;
@@ -492,10 +616,21 @@ class BFSEnactor : public EnactorBase {
                     // (the advance did not touch the visited bitmap: the bitmap itself is "visited before the level")
                     if ((retval = launch_fresh_pass(reinterpret_cast<const unsigned long long *>(ds->d_visited_mask), nullptr, out_mask))) break;
                     cur_mask = out_mask;
-                    force_bottom_up = true;
                     snapshot_valid = false;
-                    if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                     ++iteration;
+                    if (chain_len > 0) {  // (as after the heads-then-rest level)
+                        if (INSTRUMENT) {
+                            if ((retval = InstrumentEnd(stream))) break;
+                            if ((retval = util::GRError(hipStreamSynchronize(stream), "BFSEnactor instrument sync failed", __FILE__, __LINE__))) break;
+                            InstrumentCollect(in_len, in_edges, 4);
+                            if ((retval = InstrumentBegin(stream))) break;
+                        }
+                        bottom_up = true;
+                        if ((retval = run_sweep_chain(-1))) break;
+                        continue;
+                    }
+                    force_bottom_up = true;
+                    if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
                     if ((retval = work_progress.GetTailWide(static_cast<int>(iteration & 3), queue_length, queue_edges, stream))) break;
                     if (INSTRUMENT) InstrumentCollect(in_len, in_edges, 4);
                     continue;  // (selector unchanged: no queue was written)

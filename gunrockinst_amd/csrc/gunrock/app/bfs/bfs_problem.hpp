@@ -235,7 +235,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // switch-back threshold (frontier * beta < factor * nodes): the switch then needs no bitmap -> queue pass
     float emit_queue_factor = 32.0f;
     bool speculative_emit = true;  // deferred labels: the emit pass is queued right behind the closing top-down launch
-    int chain_sweeps = 1;          // bottom-up sweeps queued per host round trip
+    int chain_sweeps = 3;          // bottom-up sweeps queued per host round trip (BottomUpAutoKernel decides on the device what each
+                                   // of them does); 0 = one sweep per round trip, chosen by the host
     long long HeadPassMin() const { return head_pass_min_edges >= 0 ? head_pass_min_edges : static_cast<long long>(this->edges) / 30 + 1; }
     long long HeadPassMax() const
     {
@@ -514,7 +515,17 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // is kept, the kept levels are flushed into d_labels first (partial stores -- the price the deferral normally avoids).
     hipError_t AcquireMask(hipStream_t stream, int &idx, int hold_a = -1, int hold_b = -1)
     {
+        const int holds[2] = {hold_a, hold_b};
+        bool got = false;
+        const hipError_t rc = TryAcquireMask(stream, idx, holds, 2, got);
+        if (rc) return rc;
+        return got ? hipSuccess : util::GRError(hipErrorInvalidValue, "BFSProblem: no free frontier bitmap", __FILE__, __LINE__);
+    }
+    // the same with any number of bitmaps held; got = false when even a flush of the kept levels frees none
+    hipError_t TryAcquireMask(hipStream_t stream, int &idx, const int *holds, int n_holds, bool &got)
+    {
         hipError_t retval = hipSuccess;
+        got = true;
         if (!data_slices[0]->d_frontier_mask[1]) {  // no pool (no inverse graph): the binned level's single bitmap
             idx = 0;
             return retval;
@@ -523,14 +534,18 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         for (int round = 0; round < 2; ++round) {
             for (int t = 0; t < limit; ++t) {
                 const int cand = (mask_ring + t) % limit;
-                if (cand == hold_a || cand == hold_b || MaskKept(cand)) continue;
+                bool held = false;
+                for (int h = 0; h < n_holds; ++h) held = held || holds[h] == cand;
+                if (held || MaskKept(cand)) continue;
                 idx = cand;
                 mask_ring = (cand + 1) % limit;
                 return retval;
             }
+            if (level_masks.count == 0) break;  // nothing to flush: the holds alone fill the pool
             GR_CHECK(FlushLevelMasks(stream), "BFSProblem FlushLevelMasks failed");
         }
-        return util::GRError(hipErrorInvalidValue, "BFSProblem: no free frontier bitmap", __FILE__, __LINE__);
+        got = false;
+        return retval;
     }
     void KeepMask(int idx, VertexId label)
     {

@@ -67,8 +67,10 @@ template <typename VertexId>
 __global__ void FreshToBitmapKernel(unsigned char *d_fresh, long long nodes, unsigned long long *d_visited,
                                     const unsigned long long *d_visited_before, unsigned long long *d_frontier_out,
                                     VertexId *d_labels, VertexId label, unsigned long long *d_tail_out,
-                                    unsigned long long *d_wide, const unsigned long long *d_merge = nullptr)
+                                    unsigned long long *d_wide, const unsigned long long *d_merge = nullptr,
+                                    unsigned long long *d_tail_clear = nullptr)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d_tail_clear) *d_tail_clear = 0ull;  // ring slot of the step after next
     // One wave step = 1024 vertices: every lane loads its 16 flag bytes with ONE 16-byte load (the byte-per-lane version
     // issued 16x the load instructions and ran at 107 us for a 16 MiB map), squeezes them into 16 bits, and four
     // neighbouring lanes assemble one 64-bit bitmap word.  d_fresh is padded to a multiple of 1024 bytes (bfs_problem.hpp).
@@ -198,6 +200,13 @@ struct BottomUpArgs {
 #define GRX_BU_STEP_WORDS 8
 #endif
 constexpr int kBottomUpStepWords = GRX_BU_STEP_WORDS;
+// 64-vertex bitmap words per chunk of the compacting sweep (one word per lane: at most 64).  A pass over a chunk costs the same
+// chain of dependent round trips whether it carries 64 unvisited vertices or 6, so the chunk should hold about a wave's worth:
+// with 16 words a late level (a dozen open vertices per 1024) ran three nearly empty passes per wave.
+#ifndef GRX_BU_SPARSE_CHUNK_WORDS
+#define GRX_BU_SPARSE_CHUNK_WORDS 64
+#endif
+constexpr int kSparseChunkWords = GRX_BU_SPARSE_CHUNK_WORDS;
 
 struct __attribute__((packed, aligned(4))) Quad {
     int v[4];
@@ -334,13 +343,11 @@ __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> 
     return p_found;
 }
 
-#ifndef GRX_BU_MIN_WAVES
-#define GRX_BU_MIN_WAVES 1
-#endif
+// The dense sweep (whole workgroup).  BottomUpKernel is this body alone; BottomUpAutoKernel picks it or the compacting sweep on
+// the device.
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
-__global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpKernel(
-    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
-    Lookup in_frontier)
+__device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a,
+                                           typename ProblemData::DataSlice &slice, const Lookup &in_frontier)
 {
     typedef typename ProblemData::VertexId VertexId;
     constexpr int WAVES = THREADS / util::kWaveSize;
@@ -494,6 +501,19 @@ __global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpKernel(
     }
 }
 
+// (6 waves per SIMD: the sweep is a chain of dependent round trips per step, so resident waves are what hides them; the
+//  compiler's own choice drifted to 86 VGPRs = 5 waves when the body became a function)
+#ifndef GRX_BU_MIN_WAVES
+#define GRX_BU_MIN_WAVES 6
+#endif
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
+__global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpKernel(
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier)
+{
+    DenseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup>(a, slice, in_frontier);
+}
+
 // ---- bottom-up sweep for a nearly finished search (few unvisited vertices) ----
 // The dense kernel runs its unrolled 8-word pipeline for every step that holds ANY unvisited vertex; late in a search that is
 // every step (a few hundred thousand unvisited vertices spread over 262 K words) with a dozen busy lanes each, so a level
@@ -515,25 +535,25 @@ __device__ __forceinline__ int NthSetBit(unsigned long long x, int r)  // positi
     return pos;
 }
 
-#ifndef GRX_BUS_MIN_WAVES
-#define GRX_BUS_MIN_WAVES 1
-#endif
+// EMIT_QUEUE: the body CAN stage its finds and flush them as a queue (LDS for the staging buffer); `emit` says whether this launch
+// does.  `grid_limit`: workgroups that take part (the caller has sent the others home).
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup, bool EMIT_QUEUE>
-__global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKernel(
-    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
-    Lookup in_frontier)
+__device__ __forceinline__ void SparseSweep(const BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a,
+                                            typename ProblemData::DataSlice &slice, const Lookup &in_frontier, const bool emit,
+                                            const unsigned grid_limit)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
     constexpr int WAVES = THREADS / util::kWaveSize;
-    constexpr int CHUNK_WORDS = 16;
+    constexpr int CHUNK_WORDS = kSparseChunkWords;
+    static_assert(CHUNK_WORDS <= 64 && (CHUNK_WORDS & (CHUNK_WORDS - 1)) == 0, "one bitmap word per lane, a power of two");
     constexpr int CAPACITY = 16 * THREADS;
     typedef FrontierWriter<THREADS, EMIT_QUEUE ? CAPACITY : THREADS, VertexId, SizeT> Writer;
     __shared__ unsigned long long s_total[WAVES];
     __shared__ unsigned s_found[WAVES][CHUNK_WORDS * 2];  // found bits of the wave's current chunk, 32-bit halves
     util::DutyStamp duty(a.d_duty);
     __shared__ typename Writer::Storage s_writer;
-    if (EMIT_QUEUE) {
+    if (EMIT_QUEUE && emit) {
         Writer::Init(s_writer);
         __syncthreads();
     }
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKern
     const long long words = (static_cast<long long>(a.nodes) + 63) / 64;
     const long long chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
     const long long wave0 = (static_cast<long long>(blockIdx.x) * THREADS + tid) / util::kWaveSize;
-    const long long nwaves = static_cast<long long>(gridDim.x) * WAVES;
+    const long long nwaves = static_cast<long long>(grid_limit) * WAVES;
     const VertexId new_label = slice.iteration + 1;
     unsigned found_count = 0;
 
@@ -574,16 +594,17 @@ __global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKern
             my_with_edges = ~a.d_never[my_word];
             my_base = a.d_head_base[my_word];
         }
-        if (lane < CHUNK_WORDS * 2) s_found[wave][lane] = 0;  // wave-private rows: the wave's own program order is enough
+        for (int i = lane; i < CHUNK_WORDS * 2; i += util::kWaveSize) s_found[wave][i] = 0;  // wave-private rows: the wave's own program order is enough
         __builtin_amdgcn_wave_barrier();
 
         for (unsigned base = 0; base < total; base += util::kWaveSize) {
             const unsigned k = base + lane;
             const bool active = k < total;
             // word of the k-th unvisited vertex: number of words whose inclusive count is <= k
-            int j = 0;
+            int j = 0;  // (inc is non-decreasing over the lanes: binary search, log2(CHUNK_WORDS) shuffles)
 #pragma unroll
-            for (int w = 0; w < CHUNK_WORDS; ++w) j += (__shfl(inc, w, util::kWaveSize) <= k) ? 1 : 0;
+            for (int s = CHUNK_WORDS / 2; s; s >>= 1)
+                if (__shfl(inc, j + s - 1, util::kWaveSize) <= k) j += s;
             if (!active) j = 0;
             const unsigned before = __shfl(inc, j, util::kWaveSize) - __shfl(cnt, j, util::kWaveSize);
             const unsigned long long open_j = __shfl(my_open, j, util::kWaveSize);
@@ -617,7 +638,7 @@ __global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKern
                 if (ProblemData::MARK_PREDECESSORS) slice.d_preds[v] = parent;
                 atomicOr(&s_found[wave][2 * j + (bit >> 5)], 1u << (bit & 31));
             }
-            if (EMIT_QUEUE) {  // stage the finds for the queue (one LDS atomic per wave; past the capacity they are only counted)
+            if (EMIT_QUEUE && emit) {  // stage the finds for the queue (one LDS atomic per wave; past the capacity they are only counted)
                 const unsigned long long fm = __ballot(parent >= 0);
                 if (fm) {
                     const int leader = __ffsll(static_cast<long long>(fm)) - 1;
@@ -649,7 +670,7 @@ __global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKern
         unsigned long long *slot = util::WideTailSlot(a.d_wide);
         if (sum) atomicAdd(slot ? slot : a.d_tail_out, sum);
     }
-    if (EMIT_QUEUE) {
+    if (EMIT_QUEUE && emit) {
         const int staged = Writer::Count(s_writer);  // (the barrier above ordered it after every append)
         __syncthreads();
         if (staged > CAPACITY) {
@@ -657,6 +678,97 @@ __global__ __launch_bounds__(THREADS, GRX_BUS_MIN_WAVES) void BottomUpSparseKern
         } else {
             Writer::template Flush<true>(s_writer, staged, a.queue_out, a.d_queue_tail, a.d_overflow, a.d_fwd_row_offsets);
         }
+    }
+}
+
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup, bool EMIT_QUEUE>
+__global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier)
+{
+    SparseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup, EMIT_QUEUE>(a, slice, in_frontier, EMIT_QUEUE, gridDim.x);
+}
+
+// ---- chained sweeps: the direction rules of a bottom-up level, evaluated on the device ----
+// A bottom-up level ends with a host round trip (publish kernel, PCIe write, host spin, next launch: ~12 us) only so that the
+// host can apply four rules to the number of vertices the level found: stop (none), return to top-down (few), dense or
+// compacting sweep, and whether the compacting sweep also emits a queue.  BottomUpAutoKernel applies the same rules itself:
+// every sweep of a CHAIN adds its finds to its own set of wide counters, sweep k reads the sets of the sweeps before it (they
+// are complete: kernel boundary) and replays their decisions and its own.  The host queues several sweeps back to back and
+// makes ONE round trip for all of them; a sweep that finds the chain already over (stop / switch) exits at once (~3 us), and
+// the host replays the same rules on the published sums (SweepRule is the one definition of them) to learn what ran.
+enum SweepAction { kSweepLeft = -1, kSweepStop = 0, kSweepSwitch = 1, kSweepDense = 2, kSweepSparse = 3, kSweepSparseEmit = 4 };
+
+struct SweepRule {
+    long long with_in_edges = 0, nodes = 0;
+    double beta = 0, emit_factor = 0;
+    int sparse_div = 0;
+    // in_count: vertices of the level's input frontier; total: vertices queued so far, this frontier included
+    __host__ __device__ __forceinline__ int Decide(long long in_count, long long total, bool may_switch) const
+    {
+        if (in_count == 0) return kSweepStop;
+        if (may_switch && static_cast<double>(in_count) * beta < static_cast<double>(nodes)) return kSweepSwitch;
+        const long long open = with_in_edges - total;
+        if (sparse_div > 0 && open * sparse_div <= nodes)
+            return (static_cast<double>(in_count) * beta < emit_factor * static_cast<double>(nodes)) ? kSweepSparseEmit : kSweepSparse;
+        return kSweepDense;
+    }
+};
+
+constexpr int kChainMax = 6;        // sweeps per chain at most
+constexpr int kWideSetWords = 32 * 16;  // one set of wide counters (util::WorkProgress: 32 lines, 128 bytes apart)
+
+struct SweepChain {
+    const unsigned long long *d_sets = nullptr;  // set j: finds of the chain's sweep j; set 0: of whatever produced the first frontier
+    long long base_total = 0;   // vertices queued before the chain's first frontier
+    long long first_in = -1;    // size of the first frontier when the host knows it, else -1: the sum of set 0
+    SweepRule rule;
+    int index = 1;              // this sweep's position in the chain, from 1
+    int first_may_switch = 0;   // 0: the first sweep runs whatever the switch-back rule says (the host has just turned bottom-up)
+    int *d_log = nullptr;       // [kChainMax + 1]: the action every sweep took
+};
+
+// Whole wave; the result is wave-uniform and the same in every wave of the grid.
+__device__ __forceinline__ int ChainAction(const SweepChain &c, unsigned lane)
+{
+    unsigned long long w[kChainMax];
+#pragma unroll
+    for (int j = 0; j < kChainMax; ++j)  // (all sets the decision needs, in flight together)
+        w[j] = (j < c.index && lane < 32) ? c.d_sets[static_cast<size_t>(j) * kWideSetWords + lane * 16] : 0ull;
+    long long total = c.base_total;
+    int action = kSweepStop;
+#pragma unroll
+    for (int j = 1; j <= kChainMax; ++j) {
+        if (j <= c.index) {
+            const long long in_j = (j == 1 && c.first_in >= 0) ? c.first_in : static_cast<long long>(util::TailCount(util::WaveSum(w[j - 1])));
+            total += in_j;
+            action = c.rule.Decide(in_j, total, j > 1 || c.first_may_switch != 0);
+            if (action <= kSweepSwitch && j < c.index) return kSweepLeft;  // an earlier sweep already ended the chain
+            if (action <= kSweepSwitch) return action;
+        }
+    }
+    return action;
+}
+
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
+__global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpAutoKernel(
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier, SweepChain chain, unsigned sparse_grid, unsigned emit_grid)
+{
+    const int action = ChainAction(chain, util::LaneId());
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        chain.d_log[chain.index] = action;
+        // a sweep that emits no queue leaves its queue-tail slot zero, so that a bitmap -> queue conversion can follow directly
+        if (action >= kSweepDense && action != kSweepSparseEmit && a.d_queue_tail) *a.d_queue_tail = 0ull;
+    }
+    if (action < kSweepDense) return;  // (uniform over the grid)
+    if (action == kSweepDense) {
+        DenseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup>(a, slice, in_frontier);
+    } else {
+        const unsigned want = action == kSweepSparseEmit ? emit_grid : sparse_grid;  // (emitting: every workgroup ends with an atomic on one word)
+        const unsigned limit = want < gridDim.x ? want : gridDim.x;
+        if (blockIdx.x >= limit) return;
+        SparseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup, true>(a, slice, in_frontier, action == kSweepSparseEmit, limit);
     }
 }
 

@@ -64,12 +64,14 @@ struct HostMailbox {
     unsigned long long wide;      // packed sum of the wide tail lines (which the kernel clears again)
     unsigned long long overflow;  // *d_overflow
     unsigned long long set_value; // staging word of WorkProgress::SetTail (host -> device)
+    unsigned long long wide_set[8];  // packed sums of the further wide-counter sets (chained bottom-up sweeps; [0] unused: `wide`)
+    int chain_log[8];             // action each sweep of the last chain took (oprtr/advance/bottom_up.hpp SweepAction)
 };
 
 // One wave: mirror the enactor's device words into the mailbox, fold + re-arm the wide tail, then publish `seq`.
 static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned long long *d_sums, unsigned long long *d_wide,
                                      const int *d_overflow, HostMailbox *box, unsigned long long seq, unsigned clear_mask,
-                                     unsigned ones_mask)
+                                     unsigned ones_mask, int wide_sets, const int *d_chain_log)
 {
     // clear_mask / ones_mask: slots to zero / to set to all ones AFTER mirroring -- the re-arming an enactor
     // would otherwise do with one hipMemsetAsync per word before its next kernel
@@ -91,6 +93,21 @@ static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned 
         box->wide = w;
         box->overflow = static_cast<unsigned long long>(*d_overflow);
     }
+    if (wide_sets > 1) {  // (uniform) the sets of a sweep chain: all loads first, then fold, mirror and re-arm each
+        unsigned long long ws[7];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) ws[k - 1] = (k < wide_sets && lane < 32) ? d_wide[k * 512 + lane * 16] : 0ull;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            if (k < wide_sets) {
+                if (ws[k - 1]) d_wide[k * 512 + lane * 16] = 0ull;
+                unsigned long long t = ws[k - 1];
+                for (int o = 16; o; o >>= 1) t += __shfl_xor(t, o, 64);
+                if (lane == 0) box->wide_set[k] = t;
+            }
+        }
+        if (lane < 8) box->chain_log[lane] = d_chain_log[lane];
+    }
     __threadfence_system();
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -99,11 +116,12 @@ static __global__ void PublishKernel(unsigned long long *d_tail, const unsigned 
 // One wave: what WorkProgress::Reset + SetTail do with three fill blits and one copy blit (4-5 us each, serialised at the
 // start of every Enact) -- zero the ring, the overflow flag and the wide tail, then seed one ring slot.
 static __global__ void ArmKernel(unsigned long long *d_tail, int *d_overflow, unsigned long long *d_wide, int slots, int wide_lines,
-                                 int wide_stride, int seed_slot, unsigned long long seed_value)
+                                 int wide_stride, int seed_slot, unsigned long long seed_value, int wide_sets)
 {
     const int lane = threadIdx.x;
     if (lane < slots) d_tail[lane] = (lane == seed_slot) ? seed_value : 0ull;
-    if (lane < wide_lines) d_wide[lane * wide_stride] = 0ull;
+    if (lane < wide_lines)
+        for (int k = 0; k < wide_sets; ++k) d_wide[(k * wide_lines + lane) * wide_stride] = 0ull;
     if (lane == 0) *d_overflow = 0;
 }
 
@@ -120,7 +138,12 @@ struct WorkProgress {
     // a count (bottom-up sweep, fresh-flag pass) spread their adds over these lines; PublishKernel folds and clears them.
     static constexpr int kWideLines = 32;
     static constexpr int kWideStride = 16;  // in 8-byte words
+    // kWideSets such sets back to back: set 0 is "the" wide tail; sets 1.. take the finds of the sweeps of a chain (bottom_up.hpp)
+    static constexpr int kWideSets = 8;
+    static constexpr int kWideSetWords = kWideLines * kWideStride;
     unsigned long long *d_wide = nullptr;
+    int *d_chain_log = nullptr;            // [8] action each sweep of a chain took
+    int publish_sets = 1;                  // wide sets PublishKernel folds (enactors that chain sweeps raise it)
     // Host view.  Every blocking read-back of a BSP step is ONE tiny kernel that writes the mailbox in pinned host memory and
     // a host spin on its sequence word: the previous form (one or two hipMemcpyAsync = blit kernels of 4-5 us each, then a
     // stream query loop) cost ~20 us per level.
@@ -142,12 +165,14 @@ struct WorkProgress {
         h_sums = box->sums;
         GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
         GR_CHECK(hipMemset(d_sums, 0, sizeof(unsigned long long) * 2), "WorkProgress memset failed");
-        GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress hipMalloc d_wide failed");
+        GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideSets * kWideSetWords), "WorkProgress hipMalloc d_wide failed");
+        GR_CHECK(hipMalloc(&d_chain_log, sizeof(int) * 8), "WorkProgress hipMalloc d_chain_log failed");
+        GR_CHECK(hipMemset(d_chain_log, 0, sizeof(int) * 8), "WorkProgress memset failed");
         // Blocking clears: the enactors work on non-blocking streams, which are NOT ordered behind the null stream -- an
         // asynchronous clear issued here could land after the first search's seed (seen: a search that found nothing).
         GR_CHECK(hipMemset(d_tail, 0, sizeof(unsigned long long) * kSlots), "WorkProgress memset failed");
         GR_CHECK(hipMemset(d_overflow, 0, sizeof(int)), "WorkProgress memset failed");
-        GR_CHECK(hipMemset(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride), "WorkProgress memset failed");
+        GR_CHECK(hipMemset(d_wide, 0, sizeof(unsigned long long) * kWideSets * kWideSetWords), "WorkProgress memset failed");
         GR_CHECK(hipDeviceSynchronize(), "WorkProgress init sync failed");
         return retval;
     }
@@ -157,7 +182,7 @@ struct WorkProgress {
         hipError_t retval = hipSuccess;
         GR_CHECK(hipMemsetAsync(d_tail, 0, sizeof(unsigned long long) * kSlots, stream), "WorkProgress memset failed");
         GR_CHECK(hipMemsetAsync(d_overflow, 0, sizeof(int), stream), "WorkProgress memset failed");
-        GR_CHECK(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideLines * kWideStride, stream),
+        GR_CHECK(hipMemsetAsync(d_wide, 0, sizeof(unsigned long long) * kWideSets * kWideSetWords, stream),
                  "WorkProgress memset failed");
         return retval;
     }
@@ -167,7 +192,7 @@ struct WorkProgress {
     {
         box->overflow = 0;  // (a new search starts: forget the last search's flag)
         hipLaunchKernelGGL(ArmKernel, dim3(1), dim3(64), 0, stream, d_tail, d_overflow, d_wide, kSlots, kWideLines, kWideStride, slot & 3,
-                           PackTail(count, edges));
+                           PackTail(count, edges), kWideSets);
         return GRError(hipGetLastError(), "WorkProgress ArmKernel launch failed", __FILE__, __LINE__);
     }
 
@@ -185,7 +210,7 @@ struct WorkProgress {
         hipError_t retval = hipSuccess;
         ++seq;
         hipLaunchKernelGGL(PublishKernel, dim3(1), dim3(64), 0, stream, d_tail, d_sums, d_wide, d_overflow, box, seq, clear_mask,
-                           ones_mask);
+                           ones_mask, publish_sets, d_chain_log);
         GR_CHECK(hipGetLastError(), "WorkProgress PublishKernel launch failed");
         volatile unsigned long long *flag = &box->seq;
         unsigned spins = 0;
@@ -265,6 +290,8 @@ struct WorkProgress {
         if (box) GRError(hipHostFree(box), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
         if (d_sums) GRError(hipFree(d_sums), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (d_wide) GRError(hipFree(d_wide), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        if (d_chain_log) GRError(hipFree(d_chain_log), "WorkProgress hipFree failed", __FILE__, __LINE__);
+        d_chain_log = nullptr;
         d_tail = nullptr; d_overflow = nullptr; box = nullptr; h_tail = nullptr; h_sums = nullptr; d_sums = nullptr; d_wide = nullptr;
     }
 };

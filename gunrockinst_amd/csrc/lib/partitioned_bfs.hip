@@ -751,7 +751,7 @@ struct Pbfs : app::EnactorBase {
         L lookup{d_gathered_masks, static_cast<unsigned>(parts), static_cast<unsigned>(words_per_rank)};
         const long long words64 = (static_cast<long long>(n_local) + 63) / 64;
         if (sparse_sweep_div > 0 && open_estimate >= 0 && open_estimate * sparse_sweep_div <= static_cast<long long>(n_local)) {
-            long long sgrid = ((words64 + 15) / 16 + 3) / 4;
+            long long sgrid = ((words64 + oprtr::advance::kSparseChunkWords - 1) / oprtr::advance::kSparseChunkWords + 3) / 4;
             const long long scap = util::ResidentGrid(oprtr::advance::BottomUpSparseKernel<256, 8, 32, PbfsProblem, L, false>, 256);
             if (sgrid > scap) sgrid = scap;
             if (sgrid < 1) sgrid = 1;

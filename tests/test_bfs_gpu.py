@@ -357,17 +357,45 @@ def test_deferred_labels_equal_labels_at_discovery(deferral, mask_limit, beta, l
             p.close()
 
 
+@pytest.mark.parametrize("chain", [0, 1, 2, 3, 6])
+@pytest.mark.parametrize("beta,lite_factor,min_edges,sparse_div,emit_factor", [(0.0, -1.0, -1, 16, 32.0), (1e12, 1e9, 1, 1, 1e12),
+                                                                                (24.0, 0.0, 0, 0, 0.0), (1e12, 1e9, 0, 16, 1e12)])
+def test_chained_sweeps_decide_on_the_device_like_the_host(chain, beta, lite_factor, min_edges, sparse_div, emit_factor):
+    # bottom-up levels are queued several at a time and every sweep applies the direction rules itself (stop / back to top-down /
+    # dense / compacting / compacting + emitted queue); chain = 0 is the host-driven schedule.  Same labels and valid parents for
+    # every chain length, rule setting and both label modes; the enactor itself fails the search if its replay of the rules
+    # disagrees with what the device logged.
+    for scale, ef in [(10, 8), (16, 8), (18, 16)]:
+        g = o.rmat_seeded(scale, ef << scale)
+        deg = np.diff(g.row_offsets)
+        srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist()
+        for mark_pred, deferral, mask_limit in ((False, 1, 0), (True, 1, 4), (False, 0, 0)):
+            p = ga.BfsProblem(mark_pred, True).init(g.nodes, g.row_offsets, g.col_indices)
+            p.set_inverse_graph(beta=beta)
+            p.set_tuning(lite_factor=lite_factor)
+            p.set_head_pass(min_edges, 0 if min_edges >= 0 else -1)
+            p.set_label_deferral(deferral, mask_limit)
+            p.set_option("chain_sweeps", chain).set_option("sparse_sweep_div", sparse_div).set_option("emit_queue_factor", emit_factor)
+            for src in srcs:
+                p.reset(int(src))
+                p.enact(int(src), traversal_mode=2)
+                labels, preds = p.extract()
+                _check(g, int(src), labels, preds, p.stats())
+            p.close()
+
+
 def test_deferred_labels_on_a_long_bottom_up_run():
     # a path-like graph searched bottom-up only (alpha and beta huge): hundreds of bitmap levels through a pool of 4..12 bitmaps
     n = 3000
     rows = np.arange(n - 1, dtype=np.int32)
     g = ga.HostGraph.from_coo(n, np.concatenate([rows, rows + 1]), np.concatenate([rows + 1, rows]))
     og = o.Csr(g.nodes, g.row_offsets, g.col_indices)
-    for mask_limit in (4, 12):
+    for mask_limit, chain in ((4, 3), (12, 6), (4, 0), (5, 6)):
         p = ga.BfsProblem(True, True).init(g.nodes, g.row_offsets, g.col_indices)
         p.set_inverse_graph(alpha=1e12, beta=1e12)
         p.set_tuning(tail_edge_limit=0)
         p.set_label_deferral(1, mask_limit)
+        p.set_option("chain_sweeps", chain)
         for src in (0, n // 2):
             p.reset(src)
             p.enact(src, traversal_mode=2)

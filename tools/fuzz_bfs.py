@@ -72,6 +72,16 @@ while time.time() < t_end:
             p.set_binned_min_edges(int(rng.choice([0, 1, 1000, 1 << 23])))
             if True:
                 p.set_head_pass(int(rng.choice([-1, 1, 1000])), int(rng.choice([-1, 0])))
+        # round 3: deferred labels (on / off / a 4-bitmap pool that flushes mid-search), sweeps per round trip, direction rules,
+        # speculative emit, queue-emitting sweeps
+        p.set_label_deferral(int(rng.integers(0, 2)), int(rng.choice([0, 4, 5, 12])))
+        p.set_option("chain_sweeps", int(rng.choice([0, 1, 2, 3, 6])))
+        p.set_option("speculative_emit", int(rng.integers(0, 2)))
+        p.set_option("emit_queue_factor", float(rng.choice([0.0, 32.0, 1e9])))
+        p.set_option("sparse_sweep_div", int(rng.choice([0, 1, 16])))
+        if rng.integers(0, 2):
+            p.set_tuning(alpha=float(rng.choice([0.5, 10.0, 1e6])), beta=float(rng.choice([1e-3, 24.0, 4000.0, 1e9])),
+                         lite_factor=float(rng.choice([0.0, 12.0, 1e9])))
         srcs = [int(np.argmax(deg)), int(rng.integers(0, g.nodes)), int(rng.integers(0, g.nodes))]
         for src in srcs:
             ref, _, depth = o.bfs(g, src)
