@@ -122,7 +122,31 @@ def main():
 
     if partitioned:
         from gunrockinst_amd import multi_gpu
-        result = multi_gpu.bench(args, rank, world, local_rank)
+
+        def checker(full_labels, sources, n, m_global):
+            """rank 0, after the timed region: the whole graph rebuilt on this rank's GPU, the oracle's serial BFS (port of the
+            reference's SimpleReferenceBfs) from the first sources -- label-for-label parity of the first one and the CPU baseline"""
+            if args.no_cpu_baseline:
+                return None, None
+            from oracle import gr_oracle as o
+            gro, gci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
+            h_ro, h_ci = devgraph.to_host_csr(gro, gci)
+            del gro, gci
+            g = o.Csr(n, h_ro, h_ci)
+            cpu_edges, cpu_s, parity = 0, 0.0, None
+            for k in range(max(args.cpu_baseline_runs, 1)):
+                t0 = time.perf_counter()
+                ref, _, _ = o.bfs(g, sources[k % len(sources)])
+                cpu_s += time.perf_counter() - t0
+                cpu_edges += o.bfs_stats(g, ref)[1]
+                if k == 0:
+                    parity = bool((ref == full_labels).all()) and int(h_ci.shape[0]) == m_global
+            cpu = {"value": round(cpu_edges / (cpu_s * 1e6), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+                   "sample": "%d serial deque BFS runs (oracle port of SimpleReferenceBfs) over the whole scale-%d graph on rank 0's host, "
+                             "%.1f s CPU" % (max(args.cpu_baseline_runs, 1), args.scale, cpu_s)}
+            return parity, cpu
+
+        result = multi_gpu.bench(args, rank, world, local_rank, checker)
     elif args.primitive == "cc":
         result = bench_cc(args, torch, ga, devgraph, local_rank)
     elif args.primitive == "sssp":

@@ -230,12 +230,12 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     long long with_in_edges = 0;  // vertices that have in-edges (only they can ever be discovered bottom-up)
     // a bottom-up level runs the compacting sweep (BottomUpSparseKernel) when at most nodes / sparse_sweep_div such vertices
     // can still be unvisited (0 = never)
-    int sparse_sweep_div = 16;
+    int sparse_sweep_div = 6;  // (measured at scale-24 with 64-word chunks: 16 -> 0.348, 8 -> 0.324, 6 -> 0.321, 4 -> 0.326, 2 -> 0.45 ms per search)
     // ... and that sweep also writes its finds as the next top-down queue when its input frontier is within this factor of the
     // switch-back threshold (frontier * beta < factor * nodes): the switch then needs no bitmap -> queue pass
-    float emit_queue_factor = 32.0f;
+    float emit_queue_factor = 128.0f;
     bool speculative_emit = true;  // deferred labels: the emit pass is queued right behind the closing top-down launch
-    int chain_sweeps = 3;          // bottom-up sweeps queued per host round trip (BottomUpAutoKernel decides on the device what each
+    int chain_sweeps = 4;          // bottom-up sweeps queued per host round trip (BottomUpAutoKernel decides on the device what each
                                    // of them does); 0 = one sweep per round trip, chosen by the host
     long long HeadPassMin() const { return head_pass_min_edges >= 0 ? head_pass_min_edges : static_cast<long long>(this->edges) / 30 + 1; }
     long long HeadPassMax() const

@@ -401,6 +401,38 @@ def partition_rmat_device(scale, edge_factor, seed, rank, parts, device="cuda"):
     return devgraph.csr_from_tuples_device(1 << scale, rows, cols, undirected=True, parts=parts, rank=rank)
 
 
+def partition_rmat_exchange(scale, edge_factor, seed, comm, device="cuda"):
+    """The same slice as partition_rmat_device without the P-fold redundant generation and sort: the seeded generator is a pure
+    function of the pair index (grx_rmat_seeded_device(first, count)), so rank r generates pairs [r * ceil(pairs / P), ...) only,
+    turns every pair (a, b) into the directed tuples a -> b and b -> a (the graph is mirrored), buckets them by the OWNER of the
+    source (v mod P) and hands them over in one all-to-all; the library's COO -> CSR step then sees only tuples this rank owns
+    (self loops and duplicates are dropped there, as Csr::FromCoo does).  Returns (row_offsets, col_indices) of the local rows."""
+    from . import devgraph
+    parts, rank = comm.world, comm.rank
+    pairs = edge_factor << scale
+    per = (pairs + parts - 1) // parts
+    first = min(rank * per, pairs)
+    count = min(per, pairs - first)
+    if count > 0:
+        rows, cols = devgraph.rmat_tuples_device(scale, count, seed, first=first, device=device)
+    else:
+        rows = cols = torch.empty(0, dtype=torch.int32, device=device)
+    src = torch.cat([rows, cols])
+    dst = torch.cat([cols, rows])
+    del rows, cols
+    owner = src % parts
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=parts).tolist()
+    del owner
+    src, dst = src[order].contiguous(), dst[order].contiguous()
+    del order
+    recv_counts = comm.exchange_counts(send_counts)
+    got_src = comm.all_to_all_v(src, send_counts, recv_counts)
+    got_dst = comm.all_to_all_v(dst, send_counts, recv_counts)
+    del src, dst
+    return devgraph.csr_from_tuples_device(1 << scale, got_src, got_dst, undirected=False, parts=parts, rank=rank)
+
+
 def partition_csr_host(row_offsets, col_indices, rank, parts):
     """Split a host CSR (numpy) by the striped rule; used by tests on small graphs."""
     n = row_offsets.shape[0] - 1
@@ -432,12 +464,17 @@ def assemble_labels(comm, local_labels, n_global):
 # ------------------------------------------------------------------------------------------------------------------
 # bench leg for N > 1 (called by bench.py under torch.distributed.run)
 # ------------------------------------------------------------------------------------------------------------------
-def bench(args, rank, world, local_rank):
+def bench(args, rank, world, local_rank, checker=None):
+    """checker(full_labels, source, n, m_global) -> (parity, cpu_baseline): supplied by bench.py and called on rank 0 only, AFTER the
+    timed region (it is where the CPU oracle lives: this package never imports it)."""
     from . import devgraph
     comm = Comm()
     n = 1 << args.scale
     t0 = time.time()
-    ro, ci = partition_rmat_device(args.scale, args.edge_factor, args.seed, rank, world)
+    if os.environ.get("GUNROCK_PBFS_INGEST") == "redundant":   # every rank generates and sorts the whole tuple stream
+        ro, ci = partition_rmat_device(args.scale, args.edge_factor, args.seed, rank, world)
+    else:                                                       # each rank its share of the stream, one all-to-all by owner
+        ro, ci = partition_rmat_exchange(args.scale, args.edge_factor, args.seed, comm)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     deg = (ro[1:] - ro[:-1]).long()
@@ -498,17 +535,12 @@ def bench(args, rank, world, local_rank):
     edges_total = sum(per_src[s][1] for s in used)
     nodes_total = sum(per_src[s][0] for s in used)
 
-    # parity: rank 0 rebuilds the whole graph, runs the CPU oracle's serial BFS from the first source and compares every label
+    # parity + CPU baseline: the caller's checker (bench.py: the CPU oracle's serial BFS over the whole graph) on rank 0
     search(sources[0])
     full = assemble_labels(comm, eng.labels(), n)
-    parity = None
-    if rank == 0 and not args.no_cpu_baseline:
-        from oracle import gr_oracle as o
-        gro, gci = devgraph.rmat_csr_device(args.scale, args.edge_factor, args.seed)
-        h_ro, h_ci = devgraph.to_host_csr(gro, gci)
-        del gro, gci
-        ref, _, _ = o.bfs(o.Csr(n, h_ro, h_ci), sources[0])
-        parity = bool((ref == full).all()) and int(h_ci.shape[0]) == m_global
+    parity, cpu = None, None
+    if rank == 0 and checker is not None:
+        parity, cpu = checker(full, sources, n, m_global)
     bfs_runs = args.warmup + args.steps + len(set(used)) + 1
     eng.close()
 
@@ -533,5 +565,5 @@ def bench(args, rank, world, local_rank):
         "roofline": {"bound": "hbm", "achieved": round(balg / wall / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": round(balg / wall / 1e9 / (8000.0 * world), 5), "traffic": None,
                      "note": "whole-step wall time (kernels + collectives), all ranks"},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
     }

@@ -43,6 +43,9 @@ def _worker(rank, world, port, backend, scale, dobfs, out):
     ok = bool((ro_d.cpu().numpy() == ro_h).all()) and bool((ci_d.cpu().numpy() == ci_h).all())
 
     comm = mg.Comm()
+    # ... and so must the ingest the N-GPU bench uses: every rank generates only its share of the tuple stream, one all-to-all by owner
+    ro_x, ci_x = mg.partition_rmat_exchange(scale, 8, 0x6772, comm)
+    ok = ok and bool((ro_x.cpu().numpy() == ro_h).all()) and bool((ci_x.cpu().numpy() == ci_h).all())
     eng = mg.HipEngine(g.nodes, world, rank, ro_d, ci_d, 0)
     alpha, beta = (1e9, 1.0) if dobfs == "always" else (14.0, 24.0)
     bfs = mg.PartitionedBfs(eng, comm, g.nodes, g.edges, alpha, beta)
