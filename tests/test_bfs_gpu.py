@@ -332,7 +332,7 @@ def test_deferred_labels_equal_labels_at_discovery(deferral, mask_limit, beta, l
     # kept levels to be flushed in the middle of a search (beta huge: the search never returns to top-down, so every level after the
     # switch is a bitmap level).  The problem is reused across sources and modes, so labels of the PREVIOUS search lie in the
     # array when the next one starts -- the emit pass must overwrite every one of them, also after a top-down-only Enact.
-    for scale, ef in [(10, 8), (16, 8), (18, 16)]:
+    for scale, ef in [(10, 8), (17, 16)]:
         g = o.rmat_seeded(scale, ef << scale)
         deg = np.diff(g.row_offsets)
         srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist() + [int(np.nonzero(deg == 0)[0][0])]
@@ -357,7 +357,7 @@ def test_deferred_labels_equal_labels_at_discovery(deferral, mask_limit, beta, l
             p.close()
 
 
-@pytest.mark.parametrize("chain", [0, 1, 2, 3, 6])
+@pytest.mark.parametrize("chain", [0, 2, 6])
 @pytest.mark.parametrize("beta,lite_factor,min_edges,sparse_div,emit_factor", [(0.0, -1.0, -1, 16, 32.0), (1e12, 1e9, 1, 1, 1e12),
                                                                                 (24.0, 0.0, 0, 0, 0.0), (1e12, 1e9, 0, 16, 1e12)])
 def test_chained_sweeps_decide_on_the_device_like_the_host(chain, beta, lite_factor, min_edges, sparse_div, emit_factor):
@@ -365,7 +365,7 @@ def test_chained_sweeps_decide_on_the_device_like_the_host(chain, beta, lite_fac
     # dense / compacting / compacting + emitted queue); chain = 0 is the host-driven schedule.  Same labels and valid parents for
     # every chain length, rule setting and both label modes; the enactor itself fails the search if its replay of the rules
     # disagrees with what the device logged.
-    for scale, ef in [(10, 8), (16, 8), (18, 16)]:
+    for scale, ef in [(10, 8), (17, 16)]:
         g = o.rmat_seeded(scale, ef << scale)
         deg = np.diff(g.row_offsets)
         srcs = [o.highest_degree_node(g)[0]] + np.nonzero((deg > 0) & (deg < 4))[0][:2].tolist()
