@@ -166,10 +166,11 @@ def main():
         dist.destroy_process_group()
 
 
-_BFS_KERNELS = ("BfsResetKernel", "ArmKernel", "BitmapDiffKernel", "BitmapToQueueKernel", "BottomUpKernel", "BottomUpSparseKernel",
+_BFS_KERNELS = ("BfsResetKernel", "ArmKernel", "BitmapDiffKernel", "BitmapCopyKernel", "BitmapToQueueKernel", "BottomUpKernel", "BottomUpSparseKernel",
+                "BottomUpAutoKernel", "EmitLabelsKernel",
                 "FreshToBitmapKernel", "LoadBalancedKernel", "BinnedExpandKernel", "BinnedApplyKernel", "PersistentLevelsKernel",
                 "TailLevelsKernel", "QueueToBitmapKernel", "PublishKernel")
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def source_fingerprint():
@@ -326,11 +327,11 @@ def bench_single(args, torch, ga, devgraph, device_index):
     iprob.set_head_pass(args.head_pass_min, args.head_pass_max)
     for kv in args.opt:
         iprob.set_option(kv.split("=")[0], float(kv.split("=")[1]))
-    names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpKernel / BottomUpSparseKernel",
-             2: "BitmapToQueueKernel + PersistentLevelsKernel", 3: "advance::TailLevelsKernel",
+    names = {6: "BottomUpKernel heads-only + count-only advance + FreshToBitmapKernel", 0: "advance::LoadBalancedKernel (top-down)", 1: "advance::BottomUpAutoKernel (chain of bottom-up sweeps, dense / compacting chosen on the device)",
+             2: "BitmapToQueueKernel + PersistentLevelsKernel (+ EmitLabelsKernel queued behind it)", 3: "advance::TailLevelsKernel",
              4: "LoadBalancedKernel count-only + FreshToBitmapKernel", 5: "advance::PersistentLevelsKernel",
              7: "BinnedExpandKernel + BinnedApplyKernel + FreshToBitmapKernel + BitmapToQueueKernel (binned top-down)",
-             8: "advance::TwcLevelsKernel"}
+             8: "advance::TwcLevelsKernel", 9: "EmitLabelsKernel (when not already queued behind the closing launch)"}
     by_kind = {}
     kernel_ms, launches, balg = 0.0, 0, 0.0
     for k in range(min(args.steps, len(sources))):
