@@ -220,7 +220,13 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // traversal_mode 1 / low-degree graphs: a frontier of at most kTwcCapacity vertices and this many edges runs in the TWC
     // workgroup (oprtr/advance/twc.hpp); 0 = never
     int twc_edge_limit = 8192;
-    float lite_factor = 12.0f;  // a top-down level runs "count only" when frontier_edges * alpha * lite_factor > unexplored_edges
+    // A top-down level runs "count only" (byte stores instead of claims, then bottom-up) when frontier_edges * alpha * lite_factor >
+    // unexplored_edges.  700 = practically every level of a direction-optimizing search beyond ~40 K frontier edges at scale-24:
+    // a claimed level of 0.3-0.5 M edges costs ~50 us (memory-side atomics at 27 G/s, queue entries, scattered labels, then a read-back,
+    // a snapshot copy and a bitmap diff before the sweep), the same level counted costs ~15 us and the sweeps follow without a round
+    // trip.  Measured (ms per scale-24 search): 12 -> 0.327, 100 -> 0.319, 500 -> 0.312, 700 -> 0.311, 2000 -> 0.323, 5000 -> 0.346 (then
+    // an 11 K-edge level turns bottom-up with a frontier of a few thousand vertices: too early).
+    float lite_factor = 700.0f;
     // direction-optimizing: a level that would run count-only or bottom-up and has between min and max frontier edges starts
     // with a heads-only bottom-up pass.  -1 = automatic: edges/30 .. edges/7.8 (measured on R-MAT scale-24: below, the plain
     // count-only level is cheaper; above, the frontier is dense enough for the full bottom-up sweep to win); min 0 = never,
