@@ -159,6 +159,8 @@ _SIGNATURES = {
     "grx_pbfs_bitmap_to_queue": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "grx_pbfs_labels": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "grx_pbfs_preds": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "grx_pbfs_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "grx_pbfs_stat": (C.c_longlong, [C.c_void_p, C.c_char_p]),
     "grx_rccl_load": (C.c_int, []),
     "grx_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "grx_pbfs_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include <gunrock/app/bfs/bfs_problem.hpp>
@@ -60,8 +61,82 @@ struct PbfsProblem {
         int *d_pred_global;         // mark_pred: GLOBAL ids -> the local source that forwarded it (as a global id), else nullptr
         const int *d_recv_preds;    // mark_pred: parents that arrived with the ids being filtered, else nullptr
         int parts, rank;
+        // count-only ("marked") top-down level: one byte per GLOBAL vertex in OWNER-MAJOR order -- vertex v lives at
+        // (v mod parts) * mark_stride + v div parts -- so that what goes to one owner is one contiguous slice
+        unsigned char *d_mark = nullptr;
+        unsigned mark_stride = 0;            // bytes (= bits of the exchanged bitmap) per owner slice
+        unsigned long long mark_magic = 0;   // v div parts by a reciprocal multiplication (as StripedBitmapLookup, bottom_up.hpp)
+        unsigned mark_shift = 0;
     };
 };
+
+// Count-only top-down level of the partitioned search: every edge into a vertex this rank has not forwarded yet marks the
+// destination's byte -- a plain store, no claim, no id queue, nothing to bucket.  The bytes become per-owner bitmaps, ONE
+// all-to-all moves slice q to rank q (n / 8 bytes per rank in total, what a bottom-up level's all-gather moves), and the owner
+// ORs what it received into its visited bitmap, labelling the new bits in vertex order.  The search stays bottom-up afterwards
+// (as it does after its first sweep), so the "already forwarded" bitmap is not needed again and is not updated.
+struct MarkFunctor {
+    typedef PbfsProblem::DataSlice DataSlice;
+    static __device__ __forceinline__ bool ScreenEdge(int, int d, DataSlice *p, int = 0, int = 0)
+    {
+        return ((p->d_sent_mask[static_cast<unsigned>(d) >> 5] >> (d & 31)) & 1u) == 0;
+    }
+    static __device__ __forceinline__ bool CondEdge(int, int d, DataSlice *p, int = 0, int = 0)
+    {
+        const unsigned local = static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(d)) * p->mark_magic) >> p->mark_shift);
+        const unsigned owner = static_cast<unsigned>(d) - local * static_cast<unsigned>(p->parts);
+        p->d_mark[static_cast<size_t>(owner) * p->mark_stride + local] = 1;
+        return true;
+    }
+    static __device__ __forceinline__ void ApplyEdge(int, int, DataSlice *, int = 0, int = 0) {}
+};
+
+// mark bytes -> bits (one thread per 32-bit word of the owner-major bitmap), bytes cleared for the next such level
+__global__ void MarkBytesToBitsKernel(unsigned char *d_mark, long long words, unsigned *d_bits)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; w < words; w += stride) {
+        uint4 *src = reinterpret_cast<uint4 *>(d_mark) + 2 * w;
+        const uint4 a = src[0], b = src[1];
+        // bytes are 0 or 1: (x * 0x01020408) >> 24 gathers the low bits of a dword's four bytes
+        const unsigned lo = ((a.x * 0x01020408u) >> 24 & 0xFu) | ((a.y * 0x01020408u) >> 24 & 0xFu) << 4 |
+                            ((a.z * 0x01020408u) >> 24 & 0xFu) << 8 | ((a.w * 0x01020408u) >> 24 & 0xFu) << 12;
+        const unsigned hi = ((b.x * 0x01020408u) >> 24 & 0xFu) | ((b.y * 0x01020408u) >> 24 & 0xFu) << 4 |
+                            ((b.z * 0x01020408u) >> 24 & 0xFu) << 8 | ((b.w * 0x01020408u) >> 24 & 0xFu) << 12;
+        if (lo) src[0] = make_uint4(0, 0, 0, 0);
+        if (hi) src[1] = make_uint4(0, 0, 0, 0);
+        d_bits[w] = lo | (hi << 16);
+    }
+}
+
+// owner side: OR of the slices that arrived (slice p at d_recv + p * words), new = that & ~visited; visited, labels (vertex
+// order), the level's frontier bitmap and the count (wide tail)
+__global__ void OrSlicesKernel(const unsigned *d_recv, int parts, long long slice_words, long long words, long long n_local, unsigned *d_visited,
+                               int *d_labels, int label, unsigned long long *d_wide)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    unsigned count = 0;
+    for (long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; w < words; w += stride) {
+        unsigned cand = 0;
+        for (int p = 0; p < parts; ++p) cand |= d_recv[static_cast<size_t>(p) * slice_words + w];
+        const long long first = w * 32;
+        if (first >= n_local) cand = 0;
+        else if (first + 32 > n_local) cand &= (1u << (n_local - first)) - 1u;
+        unsigned fresh = cand & ~d_visited[w];
+        if (fresh) {
+            d_visited[w] |= fresh;  // (one thread per word: no atomics)
+            count += static_cast<unsigned>(__popc(fresh));
+            while (fresh) {
+                const int b = __ffs(fresh) - 1;
+                fresh &= fresh - 1;
+                d_labels[first + b] = label;
+            }
+        }
+    }
+    const unsigned long long total = util::WaveSum(static_cast<unsigned long long>(count));
+    if (util::LaneId() == 0 && total) atomicAdd(util::WideTailSlot(d_wide), total);
+}
+
 
 // advance functor: forward every destination at most once per rank
 struct SendFunctor {
@@ -425,7 +500,7 @@ struct Pbfs : app::EnactorBase {
     unsigned *d_never = nullptr;
     unsigned *d_head_base = nullptr;
     long long with_in_edges = 0;
-    int sparse_sweep_div = 16;           // compacting sweep when at most n_local / 16 local vertices can still be unvisited
+    int sparse_sweep_div = 6;            // compacting sweep when at most n_local / 6 local vertices can still be unvisited (64-word chunks)
     bool never_applied = false;          // step-wise path: visited |= never happened since the last Reset
     util::Frontier<int, int> queues[2];
     int *d_candidates = nullptr, *d_send = nullptr;
@@ -441,7 +516,9 @@ struct Pbfs : app::EnactorBase {
     // top-down -> bottom-up when global frontier edges * alpha > unexplored edges.  30, not the single-GPU enactor's 10: a
     // top-down level here pays its claims twice (sender's "sent" bitmap, owner's visited bitmap) plus the bucketing and the
     // exchange, so the sweep wins earlier (scale-24, 65 sources, one rank: mean 0.845 ms at 10, 0.787 at 30, 0.814 at 60)
-    double alpha = 30.0;
+    // Round 3: with count-only levels in front of the sweeps the optimum moved back to the single-GPU value (forced one-rank run,
+    // lite_factor 230: 0.71 ms at 30, 0.60 at 10..14, 0.65 at 6).
+    double alpha = 12.0;
     long long m_global = -1;             // sum of the ranks' edge counts (learned through the transport)
     int *d_recv = nullptr;               // received local ids, then (mark_pred) received parents behind them
     int recv_capacity = 0;
@@ -449,6 +526,12 @@ struct Pbfs : app::EnactorBase {
     unsigned *d_small = nullptr;         // kSmall* layout: error word, counts to send, cursors, gathered matrices
     unsigned *h_small = nullptr;         // pinned + mapped mirror of the gathered part; word [kMailWords] onwards: the mail sequence
     unsigned long long mail_seq = 0;
+    unsigned *d_mark_bits = nullptr;     // owner-major bitmap of a marked level: parts x mark words
+    // a top-down level runs count-only ("marked") when global frontier edges * alpha * lite_factor > unexplored edges (and no
+    // parents are wanted: a marked vertex does not say who marked it); 0 = never.  The single-GPU enactor's rule with the
+    // same product alpha * lite_factor (bfs_problem.hpp).
+    double lite_factor = 230.0;
+    long long marked_levels = 0;         // statistics: count-only levels run so far
     unsigned *d_visited_before = nullptr;  // local visited bitmap as it was before the last top-down level
     unsigned *d_gathered = nullptr;      // parts x (bitmap words + 2)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -554,6 +637,8 @@ struct Pbfs : app::EnactorBase {
         if (ds.d_labels) hipFree(ds.d_labels);
         if (ds.d_preds) hipFree(ds.d_preds);
         if (ds.d_pred_global) hipFree(ds.d_pred_global);
+        if (ds.d_mark) hipFree(ds.d_mark);
+        if (d_mark_bits) hipFree(d_mark_bits);
         if (d_recv) hipFree(d_recv);
         if (d_send_preds) hipFree(d_send_preds);
         if (d_small) hipFree(d_small);
@@ -807,6 +892,18 @@ struct Pbfs : app::EnactorBase {
             GR_CHECK(hipEventCreate(&ev_stop), "Pbfs hipEventCreate failed");
             sc.assign(parts, 0); so.assign(parts, 0); rc.assign(parts, 0); ro.assign(parts, 0);
         }
+        if (!ds.d_mark) {  // marked levels: bytes and bits, owner-major (a slice = whole 32-bit words of bits)
+            const unsigned slice_bits = static_cast<unsigned>(MaskWords(n_local_max)) * 32u;
+            const size_t bytes = static_cast<size_t>(parts) * slice_bits;
+            GR_CHECK(hipMalloc(&ds.d_mark, bytes), "Pbfs hipMalloc failed");
+            GR_CHECK(hipMemsetAsync(ds.d_mark, 0, bytes, stream), "Pbfs memset failed");  // (every marked level leaves them zero again)
+            GR_CHECK(hipMalloc(&d_mark_bits, bytes / 8), "Pbfs hipMalloc failed");
+            ds.mark_stride = slice_bits;
+            unsigned sh = 0;
+            while ((1u << sh) < static_cast<unsigned>(parts)) ++sh;
+            ds.mark_shift = 32 + sh;
+            ds.mark_magic = (1ull << ds.mark_shift) / static_cast<unsigned>(parts) + 1ull;
+        }
         if (mark_pred && !ds.d_pred_global) {
             GR_CHECK(hipMalloc(&ds.d_pred_global, sizeof(int) * static_cast<size_t>(n_global + 1)), "Pbfs hipMalloc failed");
             GR_CHECK(hipMalloc(&d_send_preds, sizeof(int) * static_cast<size_t>(candidate_capacity)), "Pbfs hipMalloc failed");
@@ -886,8 +983,9 @@ struct Pbfs : app::EnactorBase {
         const int wpr = MaskWords(n_local_max);  // bitmap words per rank; two trailing words carry the frontier size
         const int wpr_local = MaskWords(n_local);
         long long local_found = frontier_len;  // local vertices with edges discovered so far (sizes the compacting-sweep test)
+        bool force_bottom_up = false;          // the last level ran count-only: its discoveries exist as a bitmap only
         while (glen > 0) {
-            if (direction_optimizing && static_cast<double>(gedges) * alpha > static_cast<double>(unexplored)) {
+            if (direction_optimizing && (force_bottom_up || static_cast<double>(gedges) * alpha > static_cast<double>(unexplored))) {
                 // ---- bottom-up to the end: ONE collective per level, the all-gather of the frontier bitmaps ----
                 // the local frontier = what the last top-down level added to the local visited bitmap (zero-degree finds
                 // included: nobody can adopt them as parent); at level 0 the snapshot is the empty bitmap
@@ -926,6 +1024,54 @@ struct Pbfs : app::EnactorBase {
             unexplored -= static_cast<long long>(gedges);
             GR_CHECK(hipMemcpyAsync(d_visited_before, ds.d_visited_mask, sizeof(unsigned) * (wpr_local + 2), hipMemcpyDeviceToDevice, stream),
                      "Pbfs visited snapshot failed");
+            if (direction_optimizing && !mark_pred && lite_factor > 0 &&
+                static_cast<double>(gedges) * alpha * lite_factor > static_cast<double>(unexplored + static_cast<long long>(gedges))) {
+                // ---- count-only ("marked") level: mark -> bits -> ONE all-to-all of bitmap slices -> OR into visited ----
+                const int mark_words = MaskWords(n_local_max);  // 32-bit words per owner slice
+                if (frontier_len > 0) {
+                    oprtr::advance::AdvanceArgs<int, int> args;
+                    args.in = queues[selector];
+                    args.out = util::Frontier<int, int>();
+                    args.in_len = static_cast<int>(frontier_len);
+                    args.in_edges = static_cast<int>(frontier_edges);
+                    args.d_row_offsets = d_row_offsets;
+                    args.d_column_indices = d_col_indices;
+                    args.d_tail_out = nullptr;
+                    args.d_tail_clear = nullptr;
+                    args.d_overflow = work_progress.d_overflow;
+                    ds.iteration = level;
+                    typedef oprtr::advance::KernelPolicy<256, 4, 8, oprtr::advance::LB> MarkPolicy;
+                    if ((retval = oprtr::advance::LaunchKernel<MarkPolicy, PbfsProblem, MarkFunctor, true, true>(args, ds, 0, stream))) return retval;
+                }
+                const long long all_words = static_cast<long long>(parts) * mark_words;
+                hipLaunchKernelGGL(MarkBytesToBitsKernel, dim3(cu_count * 4), dim3(256), 0, stream, ds.d_mark, all_words, d_mark_bits);
+                GR_CHECK(hipGetLastError(), "MarkBytesToBitsKernel launch failed");
+                for (int p = 0; p < parts; ++p) {  // slice p (mark_words words) to rank p; the same from everybody
+                    sc[p] = rc[p] = static_cast<size_t>(mark_words);
+                    so[p] = ro[p] = static_cast<size_t>(p) * mark_words;
+                }
+                if (transport->AllToAllV(reinterpret_cast<const int *>(d_mark_bits), sc.data(), so.data(), reinterpret_cast<int *>(d_gathered),
+                                         rc.data(), ro.data(), stream))
+                    return hipErrorUnknown;
+                hipLaunchKernelGGL(OrSlicesKernel, dim3(cu_count * 4), dim3(256), 0, stream, d_gathered, parts, static_cast<long long>(mark_words),
+                                   static_cast<long long>(wpr_local), static_cast<long long>(n_local), ds.d_visited_mask, ds.d_labels, level + 1,
+                                   work_progress.d_wide);
+                GR_CHECK(hipGetLastError(), "OrSlicesKernel launch failed");
+                // this rank's finds -> host (the bottom-up loop below writes it behind the frontier bitmap it builds from
+                // visited XOR visited-before)
+                hipLaunchKernelGGL(FoldWideKernel, dim3(1), dim3(64), 0, stream, work_progress.d_wide, d_small + kSmallGathered,
+                                   static_cast<unsigned long long *>(nullptr));
+                GR_CHECK(hipGetLastError(), "FoldWideKernel launch failed");
+                if ((retval = Mail(d_small + kSmallGathered, 1, 1))) return retval;
+                frontier_len = h_small[0];
+                frontier_edges = 0;
+                local_found += frontier_len;
+                ++level;
+                ++levels;
+                ++marked_levels;
+                force_bottom_up = true;  // (glen stays as it is: whether anything was found shows in the first all-gather below)
+                continue;
+            }
             hipLaunchKernelGGL(PbfsArmLevelKernel, dim3(1), dim3(256), 0, stream, work_progress.d_tail, d_small, work_progress.d_overflow);
             GR_CHECK(hipGetLastError(), "PbfsArmLevelKernel launch failed");
             if (frontier_len > 0) {
@@ -1094,6 +1240,25 @@ int grx_pbfs_preds(grx_pbfs *p, int **d_preds)
     if (!p || !d_preds) return -1;
     *d_preds = p->impl.ds.d_preds;
     return 0;
+}
+
+int grx_pbfs_set_option(grx_pbfs *p, const char *name, double value)
+{
+    if (!p || !name) return -1;
+    const std::string key(name);
+    if (key == "lite_factor") p->impl.lite_factor = value;
+    else if (key == "alpha") p->impl.alpha = value;
+    else if (key == "sparse_sweep_div") p->impl.sparse_sweep_div = static_cast<int>(value);
+    else return 1;
+    return 0;
+}
+
+long long grx_pbfs_stat(grx_pbfs *p, const char *name)
+{
+    if (!p || !name) return -1;
+    const std::string key(name);
+    if (key == "marked_levels") return p->impl.marked_levels;
+    return -1;
 }
 
 int grx_rccl_load(void)

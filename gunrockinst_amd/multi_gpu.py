@@ -78,6 +78,8 @@ class Comm:
         return [int(x) for x in t.tolist()]
 
     def exchange_counts(self, send_counts):
+        if self.world == 1:  # (nothing to exchange; RCCL's all-to-all on a one-rank communicator divides by zero)
+            return [int(x) for x in send_counts]
         s = torch.tensor(send_counts, dtype=torch.int64)
         if not self.host_staged:
             s = s.cuda()
@@ -87,6 +89,8 @@ class Comm:
 
     def all_to_all_v(self, send, send_counts, recv_counts):
         """send: int32 tensor, segments in rank order.  Returns the received int32 tensor on send's device."""
+        if self.world == 1:
+            return send
         dev = send.device
         s = self._stage(send)
         r = torch.empty(int(sum(recv_counts)), dtype=torch.int32, device=s.device)
@@ -383,6 +387,14 @@ class LibraryBfs:
                          "grx_pbfs_search")
         return int(levels.value), float(ms.value)
 
+    def set_option(self, name, value):
+        """Named tuning knob of the level loop (grx_pbfs_set_option): "lite_factor", "alpha", "sparse_sweep_div"."""
+        HipEngine._check(self.lib.grx_pbfs_set_option(self._h, name.encode(), float(value)), "grx_pbfs_set_option(%s)" % name)
+        return self
+
+    def stat(self, name):
+        return int(self.lib.grx_pbfs_stat(self._h, name.encode()))
+
     def preds(self):
         ptr = C.c_void_p()
         HipEngine._check(self.lib.grx_pbfs_preds(self._h, C.byref(ptr)), "grx_pbfs_preds")
@@ -420,9 +432,12 @@ def partition_rmat_exchange(scale, edge_factor, seed, comm, device="cuda"):
     src = torch.cat([rows, cols])
     dst = torch.cat([cols, rows])
     del rows, cols
+    if parts == 1:
+        return devgraph.csr_from_tuples_device(1 << scale, src, dst, undirected=False, parts=1, rank=0)
     owner = src % parts
+    # (per-owner counts by comparison, not torch.bincount: on this ROCm build bincount raises SIGFPE for inputs of 2^28 elements)
+    send_counts = [int((owner == q).sum()) for q in range(parts)]
     order = torch.argsort(owner, stable=True)
-    send_counts = torch.bincount(owner, minlength=parts).tolist()
     del owner
     src, dst = src[order].contiguous(), dst[order].contiguous()
     del order
@@ -508,6 +523,9 @@ def bench(args, rank, world, local_rank, checker=None):
             return bfs.run(s, True, sticky_bottom_up=True)
     else:
         bfs = LibraryBfs(eng, comm, transport="callbacks" if comm.host_staged else "rccl-or-callbacks", mark_pred=False)
+        for kv in os.environ.get("GUNROCK_PBFS_OPTIONS", "").split(","):  # tuning experiments: "lite_factor=0,alpha=30"
+            if "=" in kv:
+                bfs.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
         def search(s):
             return bfs.search(s, True)[0]
@@ -557,7 +575,8 @@ def bench(args, rank, world, local_rank, checker=None):
                                                "bottom-up level on one all-gather of the frontier bitmaps per level (sizes ride along)" if not python_loop
                                                else "level loop in Python over torch.distributed (protocol model)", n, m_global),
                    "levels_src0": per_src[used[0]][2], "graph_build_s": round(build_s, 2), "backend": comm.backend,
-                   "transport": "python loop" if python_loop else bfs.transport},
+                   "transport": "python loop" if python_loop else bfs.transport,
+                   "count_only_levels_per_search": None if python_loop else round(bfs.stat("marked_levels") / max(bfs_runs, 1), 2)},
         "edges_visited_per_step": edges_total // args.steps, "nodes_visited_per_step": nodes_total // args.steps,
         "parity_vs_oracle": parity,
         "level_loop_profile_ms_per_step": ({k: round(v * 1e3 / max(bfs_runs, 1), 4) for k, v in sorted(bfs.profile.items())}

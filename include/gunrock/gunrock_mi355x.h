@@ -295,6 +295,12 @@ int grx_pbfs_set_options(grx_pbfs *p, int mark_pred, float alpha);
 /* Reset + the whole search from `src` (a GLOBAL vertex id, the same on every rank); levels = BSP levels executed;
  * elapsed_ms = device time of this rank from the reset to the last level (HIP events on the engine's stream) */
 int grx_pbfs_search(grx_pbfs *p, int src, int direction_optimizing, int *levels, float *elapsed_ms);
+/* Tuning of the level loop by name (1 = unknown name): "lite_factor" (a top-down level runs count-only -- destinations marked with
+ * byte stores, ONE all-to-all of per-owner bitmap slices, then bottom-up to the end -- when global frontier edges * alpha *
+ * lite_factor > unexplored edges and no parents are wanted; 0 = never), "alpha", "sparse_sweep_div".  grx_pbfs_stat:
+ * "marked_levels" = count-only levels run since the handle was created (-1 = unknown name). */
+int grx_pbfs_set_option(grx_pbfs *p, const char *name, double value);
+long long grx_pbfs_stat(grx_pbfs *p, const char *name);
 void grx_pbfs_destroy(grx_pbfs *p);
 
 /* library / build identification: returns a static string such as "gunrock-mi355x gfx950 ..." */

@@ -74,7 +74,7 @@ def test_partitioned_bfs_hip_engine(tmp_path, world, backend, dobfs):
     assert open(out).read() == "ok"
 
 
-def _library_worker(rank, world, port, backend, scale, dobfs, mark_pred, out):
+def _library_worker(rank, world, port, backend, scale, dobfs, mark_pred, out, lite_factor=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -95,6 +95,8 @@ def _library_worker(rank, world, port, backend, scale, dobfs, mark_pred, out):
     # exchanges handed back to gloo so that several ranks can share the GPU
     bfs = mg.LibraryBfs(eng, comm, transport="rccl" if backend == "nccl" else "callbacks", mark_pred=mark_pred,
                         alpha=1e9 if dobfs == "always" else 14.0)
+    if lite_factor is not None:
+        bfs.set_option("lite_factor", lite_factor)
     src, _ = o.highest_degree_node(g)
     deg = np.diff(g.row_offsets)
     ok = True
@@ -106,12 +108,25 @@ def _library_worker(rank, world, port, backend, scale, dobfs, mark_pred, out):
         if mark_pred:   # north_star: parents as well as depths hold on N ranks (valid parent: the paths are not unique)
             preds = mg.assemble_labels(comm, bfs.preds(), g.nodes)
             ok = ok and o.check_bfs_preds(g, s, full, preds) == 0
+    if lite_factor is not None and lite_factor >= 1e9 and dobfs and not mark_pred:
+        ok = ok and bfs.stat("marked_levels") >= 2   # the count-only level ran (sources with edges start with one)
+    if lite_factor == 0.0:
+        ok = ok and bfs.stat("marked_levels") == 0
     eng.close()
     if rank == 0:
         with open(out, "w") as f:
             f.write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend,lite_factor", [(1, "nccl", 1e9), (2, "gloo", 1e9), (3, "gloo", 1e9), (3, "gloo", 0.0), (4, "gloo", 230.0)])
+def test_library_level_loop_count_only_levels(tmp_path, world, backend, lite_factor):
+    # the count-only ("marked") top-down level of the partitioned search: byte marks, ONE all-to-all of per-owner bitmap slices, OR into
+    # the owner's visited bitmap, then bottom-up to the end.  Forced from the very first level (1e9), switched off (0), and at its default.
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_library_worker, args=(world, _free_port(), backend, 15, True, False, out, lite_factor), nprocs=world, join=True)
+    assert open(out).read() == "ok"
 
 
 @pytest.mark.parametrize("world,backend,dobfs,mark_pred", [(1, "nccl", True, False), (1, "nccl", False, True), (1, "nccl", "always", True),

@@ -43,6 +43,8 @@ def worker(rank, world, port, budget, seed, out):
         eng = mg.HipEngine(g.nodes, world, rank, ro_d, ci_d, 0)
         mark_pred = bool(rng.integers(0, 2))
         bfs = mg.LibraryBfs(eng, comm, transport="callbacks", mark_pred=mark_pred, alpha=float(rng.choice([0.0, 1.0, 1e9])))
+        bfs.set_option("lite_factor", float(rng.choice([0.0, 1.0, 230.0, 1e9])))   # count-only (marked) levels: never .. from the first level on
+        bfs.set_option("sparse_sweep_div", int(rng.choice([0, 1, 6, 16])))
         deg = np.diff(g.row_offsets)
         for src in [int(np.argmax(deg)), int(rng.integers(0, g.nodes))]:
             levels, _ = bfs.search(src, direction_optimizing=mirror and bool(rng.integers(0, 2)))
