@@ -274,8 +274,10 @@ __global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_c
 //   phase C: rows still unresolved are swept by the whole wave, 256 in-edges per step.
 template <int PROBE, int SOLO_LIMIT, typename VertexId, typename SizeT, typename Lookup>
 __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> &a, const Lookup &in_frontier, bool active, VertexId v,
-                                            unsigned lane)
+                                            unsigned lane, VertexId known_a = -1, VertexId known_b = -1)
 {
+    // known_a / known_b: in-neighbours the caller has already probed (the adjacency heads, which are entries of this row): the
+    // walk does not ask about them again -- two of the ~6-8 probes of a vertex that fails at this level
     SizeT pos = 0, end = 0;
     VertexId p_found = -1;
     if (active) {
@@ -304,7 +306,8 @@ __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> 
         fetch(nxt, pos + PROBE, active && p_found < 0 && pos + PROBE < end && done + PROBE < SOLO_LIMIT);
         bool fw[PROBE];
 #pragma unroll
-        for (int k = 0; k < PROBE; ++k) fw[k] = (active && p_found < 0 && cur[k] >= 0) ? in_frontier(cur[k]) : false;
+        for (int k = 0; k < PROBE; ++k)
+            fw[k] = (active && p_found < 0 && cur[k] >= 0 && cur[k] != known_a && cur[k] != known_b) ? in_frontier(cur[k]) : false;
 #pragma unroll
         for (int k = 0; k < PROBE; ++k)
             if (p_found < 0 && fw[k]) p_found = cur[k];
@@ -453,7 +456,14 @@ __device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemDa
                 const int jl = active ? (__ffs(more_bits) - 1) : 0;
                 more_bits &= more_bits - 1;
                 const VertexId v = static_cast<VertexId>((step * STEP_WORDS + jl) * 64 + lane);
-                const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane);
+                VertexId hx = -1, hy = -1;  // the heads of that vertex (already probed)
+#pragma unroll
+                for (int j = 0; j < STEP_WORDS; ++j)
+                    if (jl == j) {
+                        hx = head[j].x;
+                        hy = head[j].y;
+                    }
+                const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane, hx, hy);
                 const bool late = active && p_found >= 0;
                 if (late) {
                     if (!slice.defer_labels) slice.d_labels[v] = new_label;
@@ -630,7 +640,7 @@ __device__ __forceinline__ void SparseSweep(const BottomUpArgs<typename ProblemD
             }
             if (a.heads_only) more = false;
             if (__ballot(more) != 0) {
-                const VertexId late = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, more, v, lane);
+                const VertexId late = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, more, v, lane, head.x, head.y);
                 if (more && late >= 0) parent = late;
             }
             if (parent >= 0) {
