@@ -268,6 +268,15 @@ class BFSEnactor : public EnactorBase {
                                    dim3(static_cast<unsigned>(sgrid)), dim3(BU_THREADS), 0, stream, bargs, *ds, lookup);
                 return util::GRError("BottomUpSparseKernel launch failed", __FILE__, __LINE__);
             }
+            if (heads_only) {  // the lean instantiation (no row walks: fewer registers, more waves)
+                typedef oprtr::advance::BitmapLookup<VertexId> L;
+                const long long hcap = max_grid_size > 0 ? max_grid_size : util::ResidentGrid(oprtr::advance::BottomUpHeadsKernel<BU_THREADS, BFSProblem, L>, BU_THREADS);
+                if (grid > hcap) grid = hcap;
+                if (grid < 1) grid = 1;
+                hipLaunchKernelGGL((oprtr::advance::BottomUpHeadsKernel<BU_THREADS, BFSProblem, L>), dim3(static_cast<unsigned>(grid)), dim3(BU_THREADS), 0,
+                                   stream, bargs, *ds, lookup);
+                return util::GRError("BottomUpHeadsKernel launch failed", __FILE__, __LINE__);
+            }
             const long long cap = max_grid_size > 0 ? max_grid_size
                 : util::ResidentGrid(oprtr::advance::BottomUpKernel<BU_THREADS, 8, 32, BFSProblem, oprtr::advance::BitmapLookup<VertexId>>, BU_THREADS);
             if (grid > cap) grid = cap;

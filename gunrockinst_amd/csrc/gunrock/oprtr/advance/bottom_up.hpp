@@ -348,7 +348,8 @@ __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> 
 
 // The dense sweep (whole workgroup).  BottomUpKernel is this body alone; BottomUpAutoKernel picks it or the compacting sweep on
 // the device.
-template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>
+// HEADS_ONLY: the body without its row walks (the first cut of a "heads, then the rest" level): a third of the registers.
+template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup, bool HEADS_ONLY = false>
 __device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &a,
                                            typename ProblemData::DataSlice &slice, const Lookup &in_frontier)
 {
@@ -445,13 +446,13 @@ __device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemDa
                 }
             }
 
-            if (a.heads_only) more_bits = 0;
+            if (HEADS_ONLY || a.heads_only) more_bits = 0;
             // ---- rows longer than the head continue in their CSR row (from the third entry when the heads are the first two).  Only a few percent of the
             //      vertices get here, but nearly every WORD has one: walking the words one after another would put ~3
             //      dependent round trips per word back on the critical path.  Instead every lane takes ITS OWN next
             //      pending vertex (whatever word it sits in), so all pending vertices of the step advance together and
             //      the loop runs max-over-lanes(pending) times -- 1 or 2.
-            while (__ballot(more_bits != 0) != 0) {  // wave-uniform
+            while (!HEADS_ONLY && __ballot(more_bits != 0) != 0) {  // wave-uniform
                 const bool active = more_bits != 0;
                 const int jl = active ? (__ffs(more_bits) - 1) : 0;
                 more_bits &= more_bits - 1;
@@ -522,6 +523,17 @@ __global__ __launch_bounds__(THREADS, GRX_BU_MIN_WAVES) void BottomUpKernel(
     Lookup in_frontier)
 {
     DenseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup>(a, slice, in_frontier);
+}
+
+#ifndef GRX_BU_HEADS_MIN_WAVES
+#define GRX_BU_HEADS_MIN_WAVES 6
+#endif
+template <int THREADS, typename ProblemData, typename Lookup>
+__global__ __launch_bounds__(THREADS, GRX_BU_HEADS_MIN_WAVES) void BottomUpHeadsKernel(
+    BottomUpArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> a, typename ProblemData::DataSlice slice,
+    Lookup in_frontier)
+{
+    DenseSweep<THREADS, 8, 32, ProblemData, Lookup, true>(a, slice, in_frontier);
 }
 
 // ---- bottom-up sweep for a nearly finished search (few unvisited vertices) ----
