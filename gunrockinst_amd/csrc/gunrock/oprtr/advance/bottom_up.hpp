@@ -274,13 +274,19 @@ __global__ void BuildHeadsKernel(const SizeT *d_row_offsets, const VertexId *d_c
 //   phase C: rows still unresolved are swept by the whole wave, 256 in-edges per step.
 template <int PROBE, int SOLO_LIMIT, typename VertexId, typename SizeT, typename Lookup>
 __device__ __forceinline__ VertexId WalkRow(const BottomUpArgs<VertexId, SizeT> &a, const Lookup &in_frontier, bool active, VertexId v,
-                                            unsigned lane, VertexId known_a = -1, VertexId known_b = -1)
+                                            unsigned lane, VertexId known_a = -1, VertexId known_b = -1, bool extent_given = false,
+                                            SizeT given_begin = 0, SizeT given_end = 0)
 {
+    // extent_given: the caller fetched the row's extent already (one walk ahead: the fetch is the first of the walk's dependent
+    // round trips, and the vertex of the NEXT walk is known while this one runs)
     // known_a / known_b: in-neighbours the caller has already probed (the adjacency heads, which are entries of this row): the
     // walk does not ask about them again -- two of the ~6-8 probes of a vertex that fails at this level
     SizeT pos = 0, end = 0;
     VertexId p_found = -1;
-    if (active) {
+    if (extent_given) {
+        pos = given_begin + a.head_skip;
+        end = given_end;
+    } else if (active) {
         pos = a.d_inv_row_offsets[v] + a.head_skip;
         end = a.d_inv_row_offsets[v + 1];
     }
@@ -452,11 +458,25 @@ __device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemDa
             //      dependent round trips per word back on the critical path.  Instead every lane takes ITS OWN next
             //      pending vertex (whatever word it sits in), so all pending vertices of the step advance together and
             //      the loop runs max-over-lanes(pending) times -- 1 or 2.
+            // (the row extent of a lane's NEXT pending vertex is fetched while the current walk runs)
+            typedef typename ProblemData::SizeT SizeT;
+            SizeT next_begin = 0, next_end = 0;
+            if (!HEADS_ONLY && more_bits != 0) {
+                const long long nv = (step * STEP_WORDS + (__ffs(more_bits) - 1)) * 64 + lane;
+                next_begin = a.d_inv_row_offsets[nv];
+                next_end = a.d_inv_row_offsets[nv + 1];
+            }
             while (!HEADS_ONLY && __ballot(more_bits != 0) != 0) {  // wave-uniform
                 const bool active = more_bits != 0;
                 const int jl = active ? (__ffs(more_bits) - 1) : 0;
                 more_bits &= more_bits - 1;
                 const VertexId v = static_cast<VertexId>((step * STEP_WORDS + jl) * 64 + lane);
+                const SizeT row_begin = next_begin, row_end = next_end;
+                if (more_bits != 0) {
+                    const long long nv = (step * STEP_WORDS + (__ffs(more_bits) - 1)) * 64 + lane;
+                    next_begin = a.d_inv_row_offsets[nv];
+                    next_end = a.d_inv_row_offsets[nv + 1];
+                }
                 VertexId hx = -1, hy = -1;  // the heads of that vertex (already probed)
 #pragma unroll
                 for (int j = 0; j < STEP_WORDS; ++j)
@@ -464,7 +484,8 @@ __device__ __forceinline__ void DenseSweep(const BottomUpArgs<typename ProblemDa
                         hx = head[j].x;
                         hy = head[j].y;
                     }
-                const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane, hx, hy);
+                const VertexId p_found = WalkRow<PROBE, SOLO_LIMIT>(a, in_frontier, active, v, lane, hx, hy, true, active ? row_begin : 0,
+                                                                    active ? row_end : 0);
                 const bool late = active && p_found >= 0;
                 if (late) {
                     if (!slice.defer_labels) slice.d_labels[v] = new_label;
