@@ -194,7 +194,12 @@ class BFSEnactor : public EnactorBase {
 
         unsigned queue_length = problem->SourceDegree() > 0 ? 1u : 0u;
         unsigned queue_edges = static_cast<unsigned>(problem->SourceDegree());
-        if ((retval = work_progress.ResetWithTail(0, queue_length, queue_edges, stream))) return retval;
+        if (problem->armed_progress == &work_progress) {  // Reset armed this enactor's words and seeded the source (bfs_problem.hpp)
+            work_progress.box->overflow = 0;
+            problem->armed_progress = nullptr;
+        } else if ((retval = work_progress.ResetWithTail(0, queue_length, queue_edges, stream)))
+            return retval;
+        problem->arm_progress = &work_progress;  // (from the next Reset on)
         if (INSTRUMENT && (retval = DutyBegin(stream))) return retval;
 
 #ifndef GRX_CONV_GRID_MULT

@@ -64,8 +64,12 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
                                unsigned *d_snapshot, int fill_labels, long long nodes,
                                long long mask_words, VertexId src, const SizeT *d_row_offsets,
                                util::Frontier<VertexId, SizeT> queue0, SizeT *h_src_row, unsigned long long *h_src_seq,
-                               unsigned long long seq)
+                               unsigned long long seq, unsigned long long *d_arm_tail, int *d_arm_overflow, unsigned long long *d_arm_wide,
+                               int *d_arm_log)
 {
+    // d_arm_*: the device words of the enactor that ran the last search on this problem (util::WorkProgress): zeroing them and
+    // seeding ring slot 0 with the source's (1, degree) HERE saves that enactor its own arming kernel and the host wait for the
+    // source's degree in front of it (~8 us at the start of every Enact)
     typedef __attribute__((ext_vector_type(4))) int V4;
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
     const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -96,6 +100,22 @@ __global__ void BfsResetKernel(VertexId *d_labels, VertexId *d_preds, unsigned *
         d_visited[w] = never | src_bit;
         // "visited before the search": what a direction switch at level 0 diffs against; the source must survive the diff
         if (d_snapshot) d_snapshot[w] = never & ~src_bit;
+    }
+    if (d_arm_tail && blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t >= 1 && t < util::WorkProgress::kSlots) d_arm_tail[t] = 0ull;  // (slot 0 below)
+        if (t < util::WorkProgress::kWideLines)
+            for (int k = 0; k < util::WorkProgress::kWideSets; ++k) d_arm_wide[(k * util::WorkProgress::kWideLines + t) * util::WorkProgress::kWideStride] = 0ull;
+        if (t < 8) d_arm_log[t] = 0;
+        if (t == 0) {
+            *d_arm_overflow = 0;
+            unsigned long long seed = 0ull;
+            if (src >= 0) {
+                const SizeT b = d_row_offsets[src], e = d_row_offsets[src + 1];
+                if (e > b) seed = util::PackTail(1u, static_cast<unsigned>(e - b));
+            }
+            d_arm_tail[0] = seed;
+        }
     }
     if (tid == 0 && src >= 0) {
         const SizeT begin = d_row_offsets[src], end = d_row_offsets[src + 1];
@@ -448,12 +468,16 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (grid > 2048) grid = 2048;
         if (grid < 1) grid = 1;
         ++reset_seq;
+        if (!util::WorkProgress::IsLive(arm_progress)) arm_progress = nullptr;  // (that enactor is gone)
         hipLaunchKernelGGL((BfsResetKernel<VertexId, SizeT, MARK_PREDECESSORS>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream,
                            ds->d_labels, ds->d_preds, ds->d_visited_mask, direction_optimizing ? ds->d_never_mask : nullptr,
                            direction_optimizing ? ds->d_snapshot : nullptr, labels_deferred ? 0 : 1, static_cast<long long>(this->nodes),
                            static_cast<long long>(MaskWords() + 2), valid ? src : static_cast<VertexId>(-1), gs->d_row_offsets,
-                           gs->frontier_queues[0], h_src_box->row, &h_src_box->seq, reset_seq);
+                           gs->frontier_queues[0], h_src_box->row, &h_src_box->seq, reset_seq,
+                           arm_progress ? arm_progress->d_tail : nullptr, arm_progress ? arm_progress->d_overflow : nullptr,
+                           arm_progress ? arm_progress->d_wide : nullptr, arm_progress ? arm_progress->d_chain_log : nullptr);
         GR_CHECK(hipGetLastError(), "BfsResetKernel launch failed");
+        armed_progress = arm_progress;  // (the enactor that finds its own words armed skips its arming kernel)
         // No synchronisation here: everything that follows runs on the same stream, and SourceDegree() waits for the one
         // host-visible result (the source's row, which the kernel writes first).
         src_row[0] = src_row[1] = 0;
@@ -613,6 +637,10 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         emit_current = true;
         return rc;
     }
+
+    // the enactor words Reset arms (set by the enactor at its first Enact on this problem; must outlive the problem's searches)
+    util::WorkProgress *arm_progress = nullptr;
+    util::WorkProgress *armed_progress = nullptr;  // whose words the last Reset armed (nullptr: nobody's)
 
     VertexId source = -1;
     SizeT src_row[2] = {0, 0};

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <set>
 #include <cstdint>
 #include <cstring>
 
@@ -152,10 +153,20 @@ struct WorkProgress {
     unsigned long long *h_tail = nullptr;  // = box->tail
     unsigned long long seq = 0;
 
+    // WorkProgress objects whose device words exist.  A problem that arms an enactor's words from its own Reset kernel
+    // (BFSProblem) keeps a pointer to them across searches; it asks here whether the enactor is still alive before using it.
+    static std::set<const WorkProgress *> &Live()
+    {
+        static std::set<const WorkProgress *> live;
+        return live;
+    }
+    static bool IsLive(const WorkProgress *p) { return p && Live().count(p) != 0; }
+
     hipError_t Init()
     {
         hipError_t retval = hipSuccess;
         if (d_tail) return retval;
+        Live().insert(this);
         GR_CHECK(hipMalloc(&d_tail, sizeof(unsigned long long) * kSlots), "WorkProgress hipMalloc d_tail failed");
         GR_CHECK(hipMalloc(&d_overflow, sizeof(int)), "WorkProgress hipMalloc d_overflow failed");
         GR_CHECK(hipHostMalloc(reinterpret_cast<void **>(&box), sizeof(HostMailbox), hipHostMallocMapped),
@@ -285,6 +296,7 @@ struct WorkProgress {
 
     void Release()
     {
+        Live().erase(this);
         if (d_tail) GRError(hipFree(d_tail), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (d_overflow) GRError(hipFree(d_overflow), "WorkProgress hipFree failed", __FILE__, __LINE__);
         if (box) GRError(hipHostFree(box), "WorkProgress hipHostFree failed", __FILE__, __LINE__);
