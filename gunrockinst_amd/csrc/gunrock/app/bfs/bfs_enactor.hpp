@@ -365,6 +365,50 @@ class BFSEnactor : public EnactorBase {
                 queued = k;
             }
             if (queued == 0) return util::GRError(hipErrorInvalidValue, "BFSEnactor: no frontier bitmap for a bottom-up sweep", __FILE__, __LINE__);
+            // ---- the closing levels behind the chain, still without a round trip (kernel.hpp ChainedPersistentLevelsKernel): they
+            //      run when the chain ends with "back to top-down" right after a sweep that emitted its finds as a queue -- what a
+            //      scale-free search nearly always does -- and the label pass behind them reads from the gate words how many of the
+            //      chain's bitmaps were filled.  Otherwise both exit at once and the host carries on as before. ----
+            const bool closing_queued = problem->chain_closing && problem->persistent_edge_limit > 0;
+            int *d_gate = work_progress.d_chain_log + 8;
+            bool emit_queued = false;
+            if (closing_queued) {
+                oprtr::advance::PersistentArgs<VertexId, SizeT> p;
+                p.t.queue[0] = gs->frontier_queues[0];
+                p.t.queue[1] = gs->frontier_queues[1];
+                p.t.selector = selector;
+                p.t.first_iteration = it0;  // (the kernel adds the sweeps that ran)
+                p.t.d_tail = work_progress.d_tail;
+                p.t.max_levels = kTailMaxLevels;
+                p.t.d_levels_done = work_progress.LevelsDone();
+                p.t.d_level_sums = work_progress.d_sums;
+                p.t.d_row_offsets = gs->d_row_offsets;
+                p.t.d_column_indices = gs->d_column_indices;
+                p.t.d_overflow = work_progress.d_overflow;
+                p.t.edge_limit = static_cast<SizeT>(static_cast<long long>(problem->persistent_edge_limit) * 4);  // (as RunTail's closing launch)
+                p.barrier.d_counter = work_progress.BarrierCounter();
+                p.barrier.d_timeout = work_progress.BarrierTimeout();
+                p.solo_edges = problem->tail_edge_limit / 4;
+                p.unexplored_edges = unexplored_edges;
+                p.switch_factor = 0.0;
+                oprtr::advance::SweepChain chain;
+                chain.d_sets = work_progress.d_wide;
+                chain.base_total = base_total;
+                chain.first_in = first_in;
+                chain.rule = sweep_rule;
+                chain.index = queued;
+                chain.first_may_switch = 0;
+                chain.d_log = work_progress.d_chain_log;
+                if ((rc = oprtr::advance::LaunchChainedPersistentLevels<PersistentPolicy, BFSProblem, BfsFunctor>(
+                         p, *ds, cu_count, chain, queued, it0, reinterpret_cast<const int *>(work_progress.AuxTail()), d_gate, stream)))
+                    return rc;
+                if (deferring && problem->speculative_emit && problem->level_masks.count + queued <= app::bfs::kLevelMasks) {
+                    VertexId labels[oprtr::advance::kChainMax];
+                    for (int k = 1; k <= queued; ++k) labels[k - 1] = static_cast<VertexId>(it0 + k);
+                    if ((rc = problem->EmitLabelsGated(stream, masks + 1, labels, queued, d_gate))) return rc;
+                    emit_queued = true;
+                }
+            }
             if (INSTRUMENT && (rc = InstrumentEnd(stream))) return rc;
             if ((rc = work_progress.Sync(stream))) return rc;
             // ---- replay (the same SweepRule on the same numbers) ----
@@ -397,6 +441,26 @@ class BFSEnactor : public EnactorBase {
                 if ((rc = work_progress.ClearAux(stream))) return rc;
             }
             if (INSTRUMENT) InstrumentCollect(static_cast<long long>(first_in >= 0 ? first_in : 0), 0, 1);
+            // ---- did the closing levels run?  (the kernel's own test, replayed) ----
+            if (closing_queued && ran >= 1 && queue_emitted && queue_length > 0 &&
+                sweep_rule.Decide(next_in, total + next_in, true) == oprtr::advance::kSweepSwitch) {
+                if (work_progress.HostBarrierTimedOut())
+                    return util::GRError(hipErrorLaunchTimeOut, "BFSEnactor persistent levels kernel: grid barrier timed out", __FILE__, __LINE__);
+                const int done = work_progress.HostLevelsDone();
+                iteration += done;
+                selector ^= (done & 1);
+                queue_length = util::TailCount(work_progress.h_tail[iteration & 3]);
+                queue_edges = util::TailEdges(work_progress.h_tail[iteration & 3]);
+                enactor_stats.total_queued += static_cast<long long>(work_progress.h_sums[0]);
+                enactor_stats.total_edges_queued += static_cast<long long>(work_progress.h_sums[1]);
+                unexplored_edges -= static_cast<long long>(work_progress.h_sums[1]);
+                bottom_up = false;
+                queue_emitted = false;
+                out_slot_clean = false;
+                snapshot_valid = false;
+                // (the gated label pass ran behind them; it stands unless the search goes on)
+                if (emit_queued) problem->emit_current = queue_length == 0;
+            }
             return rc;
         };
         // count-only top-down advance over the current queue: unvisited destinations get their d_fresh byte set

@@ -149,6 +149,10 @@ struct LevelMaskList {
     const unsigned long long *mask[kLevelMasks];
     VertexId label[kLevelMasks];
     int count = 0;
+    // a pass queued behind a chain of sweeps before the host knows how the chain ended: entries [chain_first, count) are the
+    // chain's bitmaps in order, of which only the first d_gate[1] were filled; d_gate[0] == 0: do not run at all
+    int chain_first = 0;
+    const int *d_gate = nullptr;
 };
 
 // KMAX = bitmaps the kernel reads (entries past levels.count repeat entry 0: the same bit gives the same label).  All KMAX + 2
@@ -159,6 +163,11 @@ __global__ __launch_bounds__(256) void EmitLabelsKernel(LevelMaskList<VertexId> 
                                                         const unsigned long long *d_never, long long nodes, VertexId src, VertexId *d_labels)
 {
     typedef __attribute__((ext_vector_type(4))) int V4;
+    int valid = KMAX;  // entries that count (the padding repeats entry 0: harmless)
+    if (levels.d_gate) {  // (uniform)
+        if (levels.d_gate[0] == 0) return;
+        valid = levels.chain_first + levels.d_gate[1];
+    }
     const long long quads = (nodes + 3) / 4;  // four consecutive vertices per lane: one 16-byte store
     const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
     for (long long q = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; q < quads; q += stride) {
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void EmitLabelsKernel(LevelMaskList<VertexId> 
         unsigned covered = 0;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            const unsigned m = static_cast<unsigned>(mw[k] >> sh) & 0xFu;
+            const unsigned m = (k < valid) ? static_cast<unsigned>(mw[k] >> sh) & 0xFu : 0u;
             covered |= m;
             const VertexId l = levels.label[k];
             if (m & 1u) out[0] = l;
@@ -260,6 +269,7 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // ... and that sweep also writes its finds as the next top-down queue when its input frontier is within this factor of the
     // switch-back threshold (frontier * beta < factor * nodes): the switch then needs no bitmap -> queue pass
     float emit_queue_factor = 128.0f;
+    bool chain_closing = true;     // the closing top-down levels (and the label pass) are queued behind a chain of sweeps, gated on the device
     bool speculative_emit = true;  // deferred labels: the emit pass is queued right behind the closing top-down launch
     int chain_sweeps = 4;          // bottom-up sweeps queued per host round trip (BottomUpAutoKernel decides on the device what each
                                    // of them does); 0 = one sweep per round trip, chosen by the host
@@ -591,7 +601,8 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (grid > (1 << 20)) grid = 1 << 20;
         if (grid < 1) grid = 1;
         LevelMaskList<VertexId> list = level_masks;
-        const int kmax = list.count == 0 ? 0 : (list.count <= 4 ? 4 : (list.count <= 8 ? 8 : kLevelMasks));
+        // (one instantiation per list length up to 8: every extra bitmap is one more load per lane of a pass that is all loads and stores)
+        const int kmax = list.count <= 8 ? list.count : kLevelMasks;
         for (int k = list.count; k < kmax; ++k) {  // padding: entry 0 again
             list.mask[k] = list.mask[0];
             list.label[k] = list.label[0];
@@ -600,10 +611,13 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         const unsigned long long *nev = reinterpret_cast<const unsigned long long *>(ds->d_never_mask);
         const long long n = static_cast<long long>(this->nodes);
         const dim3 g(static_cast<unsigned>(grid)), b(256);
-        if (kmax == 0) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 0>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
-        else if (kmax == 4) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 4>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
-        else if (kmax == 8) hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, 8>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
-        else hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, kLevelMasks>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+#define GRX_EMIT_CASE(K) case K: hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, K>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels); break;
+        switch (kmax) {
+            GRX_EMIT_CASE(0) GRX_EMIT_CASE(1) GRX_EMIT_CASE(2) GRX_EMIT_CASE(3) GRX_EMIT_CASE(4) GRX_EMIT_CASE(5) GRX_EMIT_CASE(6) GRX_EMIT_CASE(7)
+            GRX_EMIT_CASE(8)
+            default: hipLaunchKernelGGL((EmitLabelsKernel<VertexId, FULL, kLevelMasks>), g, b, 0, stream, list, vis, nev, n, src, ds->d_labels);
+        }
+#undef GRX_EMIT_CASE
         level_masks.count = 0;
         return util::GRError(hipGetLastError(), "EmitLabelsKernel launch failed", __FILE__, __LINE__);
     }
@@ -628,6 +642,20 @@ struct BFSProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // bitmaps and the deferral stay as they are, so that a search that does go on simply ends with another pass -- the first
     // one wrote nothing wrong (labels of levels that existed), the second one covers the rest.  The caller clears emit_current
     // when anything is discovered after this.
+    // ... and the same pass queued behind a CHAIN of sweeps and the closing levels that follow it on the device
+    // (kernel.hpp ChainedPersistentLevelsKernel): the chain's bitmaps go in as candidates, the gate words say how many were filled
+    hipError_t EmitLabelsGated(hipStream_t stream, const int *chain_masks, const VertexId *chain_labels, int chain_count, const int *d_gate)
+    {
+        if (!labels_deferred || !speculative_emit) return hipSuccess;
+        if (level_masks.count + chain_count > kLevelMasks) return hipSuccess;  // (no room in the list: the ordinary pass will do)
+        const LevelMaskList<VertexId> keep = level_masks;
+        level_masks.chain_first = level_masks.count;
+        for (int k = 0; k < chain_count; ++k) KeepMask(chain_masks[k], chain_labels[k]);
+        level_masks.d_gate = d_gate;
+        const hipError_t rc = LaunchEmit<true>(stream, (source >= 0 && source < this->nodes) ? source : static_cast<VertexId>(-1));
+        level_masks = keep;
+        return rc;
+    }
     hipError_t EmitLabelsSpeculative(hipStream_t stream)
     {
         if (!labels_deferred || !speculative_emit) return hipSuccess;

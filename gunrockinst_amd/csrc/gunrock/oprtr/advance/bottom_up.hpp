@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <gunrock/oprtr/advance/sweep_chain.hpp>
 #include <gunrock/oprtr/frontier_writer.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
@@ -730,67 +731,6 @@ __global__ __launch_bounds__(THREADS) void BottomUpSparseKernel(
     Lookup in_frontier)
 {
     SparseSweep<THREADS, PROBE, SOLO_LIMIT, ProblemData, Lookup, EMIT_QUEUE>(a, slice, in_frontier, EMIT_QUEUE, gridDim.x);
-}
-
-// ---- chained sweeps: the direction rules of a bottom-up level, evaluated on the device ----
-// A bottom-up level ends with a host round trip (publish kernel, PCIe write, host spin, next launch: ~12 us) only so that the
-// host can apply four rules to the number of vertices the level found: stop (none), return to top-down (few), dense or
-// compacting sweep, and whether the compacting sweep also emits a queue.  BottomUpAutoKernel applies the same rules itself:
-// every sweep of a CHAIN adds its finds to its own set of wide counters, sweep k reads the sets of the sweeps before it (they
-// are complete: kernel boundary) and replays their decisions and its own.  The host queues several sweeps back to back and
-// makes ONE round trip for all of them; a sweep that finds the chain already over (stop / switch) exits at once (~3 us), and
-// the host replays the same rules on the published sums (SweepRule is the one definition of them) to learn what ran.
-enum SweepAction { kSweepLeft = -1, kSweepStop = 0, kSweepSwitch = 1, kSweepDense = 2, kSweepSparse = 3, kSweepSparseEmit = 4 };
-
-struct SweepRule {
-    long long with_in_edges = 0, nodes = 0;
-    double beta = 0, emit_factor = 0;
-    int sparse_div = 0;
-    // in_count: vertices of the level's input frontier; total: vertices queued so far, this frontier included
-    __host__ __device__ __forceinline__ int Decide(long long in_count, long long total, bool may_switch) const
-    {
-        if (in_count == 0) return kSweepStop;
-        if (may_switch && static_cast<double>(in_count) * beta < static_cast<double>(nodes)) return kSweepSwitch;
-        const long long open = with_in_edges - total;
-        if (sparse_div > 0 && open * sparse_div <= nodes)
-            return (static_cast<double>(in_count) * beta < emit_factor * static_cast<double>(nodes)) ? kSweepSparseEmit : kSweepSparse;
-        return kSweepDense;
-    }
-};
-
-constexpr int kChainMax = 6;        // sweeps per chain at most
-constexpr int kWideSetWords = 32 * 16;  // one set of wide counters (util::WorkProgress: 32 lines, 128 bytes apart)
-
-struct SweepChain {
-    const unsigned long long *d_sets = nullptr;  // set j: finds of the chain's sweep j; set 0: of whatever produced the first frontier
-    long long base_total = 0;   // vertices queued before the chain's first frontier
-    long long first_in = -1;    // size of the first frontier when the host knows it, else -1: the sum of set 0
-    SweepRule rule;
-    int index = 1;              // this sweep's position in the chain, from 1
-    int first_may_switch = 0;   // 0: the first sweep runs whatever the switch-back rule says (the host has just turned bottom-up)
-    int *d_log = nullptr;       // [kChainMax + 1]: the action every sweep took
-};
-
-// Whole wave; the result is wave-uniform and the same in every wave of the grid.
-__device__ __forceinline__ int ChainAction(const SweepChain &c, unsigned lane)
-{
-    unsigned long long w[kChainMax];
-#pragma unroll
-    for (int j = 0; j < kChainMax; ++j)  // (all sets the decision needs, in flight together)
-        w[j] = (j < c.index && lane < 32) ? c.d_sets[static_cast<size_t>(j) * kWideSetWords + lane * 16] : 0ull;
-    long long total = c.base_total;
-    int action = kSweepStop;
-#pragma unroll
-    for (int j = 1; j <= kChainMax; ++j) {
-        if (j <= c.index) {
-            const long long in_j = (j == 1 && c.first_in >= 0) ? c.first_in : static_cast<long long>(util::TailCount(util::WaveSum(w[j - 1])));
-            total += in_j;
-            action = c.rule.Decide(in_j, total, j > 1 || c.first_may_switch != 0);
-            if (action <= kSweepSwitch && j < c.index) return kSweepLeft;  // an earlier sweep already ended the chain
-            if (action <= kSweepSwitch) return action;
-        }
-    }
-    return action;
 }
 
 template <int THREADS, int PROBE, int SOLO_LIMIT, typename ProblemData, typename Lookup>

@@ -27,6 +27,7 @@
 
 #include <gunrock/oprtr/advance/binned.hpp>
 #include <gunrock/oprtr/advance/functor_hooks.hpp>
+#include <gunrock/oprtr/advance/sweep_chain.hpp>
 #include <gunrock/oprtr/frontier_writer.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/error_utils.hpp>
@@ -823,8 +824,8 @@ struct PersistentArgs {
 };
 
 template <typename KernelPolicy, typename ProblemData, typename Functor>
-__global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
-    PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> p, typename ProblemData::DataSlice slice)
+__device__ __forceinline__ void PersistentLevelsBody(const PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &p,
+                                                     typename ProblemData::DataSlice &slice, const long long first_iteration)
 {
     typedef typename ProblemData::VertexId VertexId;
     typedef typename ProblemData::SizeT SizeT;
@@ -837,7 +838,8 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
     unsigned tile_tag;
     InitOwnerMarks<KernelPolicy>(sh, tile_tag);
     int selector = t.selector;
-    long long iteration = t.first_iteration;
+    long long iteration = first_iteration;  // (a parameter, not p.t.first_iteration: writing into the by-value argument block
+                                            //  would move the whole block to scratch memory)
     long long unexplored = p.unexplored_edges;
     int done = 0;
     unsigned epoch = 0;
@@ -905,6 +907,37 @@ __global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
     }
 }
 
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void PersistentLevelsKernel(
+    PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> p, typename ProblemData::DataSlice slice)
+{
+    PersistentLevelsBody<KernelPolicy, ProblemData, Functor>(p, slice, p.t.first_iteration);
+}
+
+// The same levels queued BEHIND a chain of bottom-up sweeps, before the host knows how the chain ended (sweep_chain.hpp): they
+// run only when the chain ended with "return to top-down" right after a sweep that emitted its finds as a queue (and the
+// queue is intact); the BSP level they start at follows from where the chain ended.  d_gate[0] = 1 when they ran (the label
+// pass queued behind reads it), d_gate[1] = sweeps of the chain that ran.
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+__global__ __launch_bounds__(KernelPolicy::THREADS) void ChainedPersistentLevelsKernel(
+    PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> p, typename ProblemData::DataSlice slice,
+    SweepChain chain, int sweeps, long long first_level, const int *d_queue_invalid, int *d_gate)
+{
+    const ChainEnd end = ChainOutcome(chain, sweeps, util::LaneId());
+    const bool run = end.action == kSweepSwitch && end.end >= 2 && end.prev_action == kSweepSparseEmit && *d_queue_invalid == 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d_gate[0] = run ? 1 : 0;
+        d_gate[1] = end.end - 1;
+        if (!run) {
+            *p.t.d_levels_done = 0;
+            p.t.d_level_sums[0] = 0ull;
+            p.t.d_level_sums[1] = 0ull;
+        }
+    }
+    if (!run) return;  // (the same in every workgroup)
+    PersistentLevelsBody<KernelPolicy, ProblemData, Functor>(p, slice, first_level + (end.end - 1));
+}
+
 // cooperative: launch through hipLaunchCooperativeKernel, whose launch-time check rejects a grid beyond the occupancy query
 // (+15-19 us of host time per launch on MI355X; residency itself is the same as a plain launch's, so it is off by default and
 // the barrier's timeout word stays the run-time safety net against CUs taken by another stream or process).
@@ -930,6 +963,19 @@ hipError_t LaunchPersistentLevels(const PersistentArgs<typename ProblemData::Ver
     hipLaunchKernelGGL((PersistentLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(grid), dim3(KernelPolicy::THREADS), 0,
                        stream, args, slice);
     return util::GRError("advance::PersistentLevelsKernel launch failed", __FILE__, __LINE__);
+}
+
+template <typename KernelPolicy, typename ProblemData, typename Functor>
+hipError_t LaunchChainedPersistentLevels(const PersistentArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
+                                         const typename ProblemData::DataSlice &slice, int cu_count, const SweepChain &chain, int sweeps,
+                                         long long first_level, const int *d_queue_invalid, int *d_gate, hipStream_t stream)
+{
+    int grid = util::ResidentGrid(ChainedPersistentLevelsKernel<KernelPolicy, ProblemData, Functor>, KernelPolicy::THREADS);
+    if (grid > cu_count) grid = cu_count;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((ChainedPersistentLevelsKernel<KernelPolicy, ProblemData, Functor>), dim3(grid), dim3(KernelPolicy::THREADS), 0, stream, args,
+                       slice, chain, sweeps, first_level, d_queue_invalid, d_gate);
+    return util::GRError("advance::ChainedPersistentLevelsKernel launch failed", __FILE__, __LINE__);
 }
 
 template <typename KernelPolicy, typename ProblemData, typename Functor>

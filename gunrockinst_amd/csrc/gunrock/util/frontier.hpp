@@ -143,7 +143,8 @@ struct WorkProgress {
     static constexpr int kWideSets = 8;
     static constexpr int kWideSetWords = kWideLines * kWideStride;
     unsigned long long *d_wide = nullptr;
-    int *d_chain_log = nullptr;            // [8] action each sweep of a chain took
+    int *d_chain_log = nullptr;            // [8] action each sweep of a chain took; [8], [9]: gate words of the kernels queued behind
+                                           // a chain (did the closing levels run; how many sweeps ran)
     int publish_sets = 1;                  // wide sets PublishKernel folds (enactors that chain sweeps raise it)
     // Host view.  Every blocking read-back of a BSP step is ONE tiny kernel that writes the mailbox in pinned host memory and
     // a host spin on its sequence word: the previous form (one or two hipMemcpyAsync = blit kernels of 4-5 us each, then a
@@ -177,8 +178,8 @@ struct WorkProgress {
         GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * 2), "WorkProgress hipMalloc d_sums failed");
         GR_CHECK(hipMemset(d_sums, 0, sizeof(unsigned long long) * 2), "WorkProgress memset failed");
         GR_CHECK(hipMalloc(&d_wide, sizeof(unsigned long long) * kWideSets * kWideSetWords), "WorkProgress hipMalloc d_wide failed");
-        GR_CHECK(hipMalloc(&d_chain_log, sizeof(int) * 8), "WorkProgress hipMalloc d_chain_log failed");
-        GR_CHECK(hipMemset(d_chain_log, 0, sizeof(int) * 8), "WorkProgress memset failed");
+        GR_CHECK(hipMalloc(&d_chain_log, sizeof(int) * 16), "WorkProgress hipMalloc d_chain_log failed");
+        GR_CHECK(hipMemset(d_chain_log, 0, sizeof(int) * 16), "WorkProgress memset failed");
         // Blocking clears: the enactors work on non-blocking streams, which are NOT ordered behind the null stream -- an
         // asynchronous clear issued here could land after the first search's seed (seen: a search that found nothing).
         GR_CHECK(hipMemset(d_tail, 0, sizeof(unsigned long long) * kSlots), "WorkProgress memset failed");

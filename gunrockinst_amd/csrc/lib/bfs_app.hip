@@ -138,6 +138,7 @@ struct BfsRunnerT : BfsRunner {
         else if (key == "sparse_sweep_div") problem.sparse_sweep_div = static_cast<int>(value);
         else if (key == "speculative_emit") problem.speculative_emit = value != 0.0;
         else if (key == "chain_sweeps") problem.chain_sweeps = static_cast<int>(value);
+        else if (key == "chain_closing") problem.chain_closing = value != 0.0;
         else return 1;
         return 0;
     }

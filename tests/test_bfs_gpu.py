@@ -376,6 +376,7 @@ def test_chained_sweeps_decide_on_the_device_like_the_host(chain, beta, lite_fac
             p.set_head_pass(min_edges, 0 if min_edges >= 0 else -1)
             p.set_label_deferral(deferral, mask_limit)
             p.set_option("chain_sweeps", chain).set_option("sparse_sweep_div", sparse_div).set_option("emit_queue_factor", emit_factor)
+            p.set_option("chain_closing", 1 if mark_pred else 0)   # (the closing levels queued behind the chain, or launched by the host)
             for src in srcs:
                 p.reset(int(src))
                 p.enact(int(src), traversal_mode=2)

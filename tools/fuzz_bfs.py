@@ -77,6 +77,7 @@ while time.time() < t_end:
         p.set_label_deferral(int(rng.integers(0, 2)), int(rng.choice([0, 4, 5, 12])))
         p.set_option("chain_sweeps", int(rng.choice([0, 1, 2, 3, 6])))
         p.set_option("speculative_emit", int(rng.integers(0, 2)))
+        p.set_option("chain_closing", int(rng.integers(0, 2)))
         p.set_option("emit_queue_factor", float(rng.choice([0.0, 32.0, 1e9])))
         p.set_option("sparse_sweep_div", int(rng.choice([0, 1, 16])))
         if rng.integers(0, 2):
