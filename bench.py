@@ -167,7 +167,7 @@ def main():
 
 
 _BFS_KERNELS = ("BfsResetKernel", "ArmKernel", "BitmapDiffKernel", "BitmapCopyKernel", "BitmapToQueueKernel", "BottomUpKernel", "BottomUpSparseKernel",
-                "BottomUpAutoKernel", "EmitLabelsKernel",
+                "BottomUpAutoKernel", "BottomUpHeadsKernel", "ChainedPersistentLevelsKernel", "EmitLabelsKernel",
                 "FreshToBitmapKernel", "LoadBalancedKernel", "BinnedExpandKernel", "BinnedApplyKernel", "PersistentLevelsKernel",
                 "TailLevelsKernel", "QueueToBitmapKernel", "PublishKernel")
 PROFILE_TAG = "r03"
