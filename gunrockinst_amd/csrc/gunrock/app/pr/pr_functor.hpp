@@ -26,10 +26,13 @@ struct PRFunctor {
 
     // pull form: s_id = the vertex that receives, d_id = one of its in-neighbours.  Side-effect free, so it is evaluated for a
     // whole tile before any result is used (advance hook).
-    static __device__ __forceinline__ bool ScreenEdge(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
-                                                      VertexId /*e_id_in*/ = 0)
+    // The reference's rule "the edge takes part when both ends still have out-edges" (pr_functor.cuh:52-55) needs no test per
+    // edge here: a peeled in-neighbour's contribution is exactly 0 (ContribKernel; only surviving vertices are ever updated), and
+    // the receiving vertex is in the frontier because it survived.  (Round 2 tested d_degrees[d_id] per edge: a second random
+    // 4-byte gather -- one more 64-byte sector -- next to contrib[d_id]; adding the 0 instead is bit-identical.)
+    static __device__ __forceinline__ bool ScreenEdge(VertexId, VertexId, DataSlice *, VertexId /*e_id*/ = 0, VertexId /*e_id_in*/ = 0)
     {
-        return problem->d_degrees[d_id] > 0 && problem->d_degrees[s_id] > 0;
+        return true;
     }
     static __device__ __forceinline__ bool CondEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) { return true; }
     static __device__ __forceinline__ void ApplyEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) {}
