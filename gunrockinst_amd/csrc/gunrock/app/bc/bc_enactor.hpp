@@ -26,6 +26,27 @@ namespace gunrock {
 namespace app {
 namespace bc {
 
+// d_packed[v] = (label, 1 / sigma): the term a vertex offers before anything was accumulated into its delta (deltas are zero)
+template <typename VertexId, typename Value>
+__global__ void PackTermsKernel(const VertexId *d_labels, const Value *d_sigmas, int2 *d_packed, long long nodes)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v < nodes; v += stride) {
+        const VertexId l = d_labels[v];
+        d_packed[v] = make_int2(l, l >= 0 ? __float_as_int(static_cast<Value>(1) / d_sigmas[v]) : 0);
+    }
+}
+// ... and (1 + delta) / sigma once the deltas of a level's vertices are final
+template <typename VertexId, typename Value>
+__global__ void RefreshTermsKernel(const VertexId *d_queue, long long length, const Value *d_sigmas, const Value *d_deltas, int2 *d_packed)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < length; i += stride) {
+        const VertexId v = d_queue[i];
+        d_packed[v].y = __float_as_int((static_cast<Value>(1) + d_deltas[v]) / d_sigmas[v]);
+    }
+}
+
 template <bool INSTRUMENT>
 class BCEnactor : public EnactorBase {
    public:
@@ -108,6 +129,11 @@ class BCEnactor : public EnactorBase {
         }
         enactor_stats.iteration = iteration;
 
+        // (label, 1 / sigma) side by side for the backward gathers (bc_functor.hpp BackwardReduceFunctor)
+        hipLaunchKernelGGL((PackTermsKernel<VertexId, Value>), dim3(util::MemsetGrid(problem->nodes)), dim3(256), 0, stream, ds->d_labels,
+                           ds->d_sigmas, ds->d_packed, static_cast<long long>(problem->nodes));
+        if ((retval = util::GRError("PackTermsKernel launch failed", __FILE__, __LINE__))) return retval;
+
         // ---- backward: dependencies, deepest recorded frontier first.  The recorded levels are the ones that have out-edges: the
         // last one can still have children -- vertices WITHOUT out-edges (sinks of a directed graph), which the frontier writer
         // does not enqueue -- so it takes part.  (Level 0 is the source alone, which accumulates nothing: bc_functor.cuh:205-208.)
@@ -130,6 +156,12 @@ class BCEnactor : public EnactorBase {
                                                        true>(args, *ds, static_cast<const Value *>(nullptr), ds->d_deltas, max_grid_size,
                                                              stream, static_cast<long long>(problem->nodes), false)))
                 return retval;
+            // this level's deltas are final: the term its vertices offer to the level above
+            if (level > 1) {
+                hipLaunchKernelGGL((RefreshTermsKernel<VertexId, Value>), dim3(util::MemsetGrid(level_len[level])), dim3(256), 0, stream,
+                                   q.v + level_offset[level], static_cast<long long>(level_len[level]), ds->d_sigmas, ds->d_deltas, ds->d_packed);
+                if ((retval = util::GRError("RefreshTermsKernel launch failed", __FILE__, __LINE__))) return retval;
+            }
         }
         // dependencies are final: fold them into the running centralities, once per vertex
         hipLaunchKernelGGL((AccumulateKernel<Value>), dim3(util::MemsetGrid(problem->nodes)), dim3(256), 0, stream, ds->d_bc_values,

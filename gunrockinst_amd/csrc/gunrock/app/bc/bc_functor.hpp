@@ -144,13 +144,16 @@ struct BackwardReduceFunctor {
     static __device__ __forceinline__ void ApplyEdge(VertexId, VertexId, DataSlice *, VertexId = 0, VertexId = 0) {}
     // the value an edge s -> d contributes to delta[s] -- zero unless d lies one level below s.  Branch-free: an edge that fails the label test reads the source's own entries (hot lines) instead of
     // the destination's, so a tile's label loads and then its sigma / delta loads are in flight together.
+    // Round 3: label and term come from ONE 8-byte gather of d_packed[d] (BCEnactor packs (label, 1 / sigma) after the forward phase
+    // and refreshes the term of a level's vertices once their deltas are final); the three separate 4-byte gathers were up to three
+    // 64-byte sectors per edge.  The division happens once per vertex, not once per edge.
     static __device__ __forceinline__ Value ReduceValue(VertexId s_id, VertexId d_id, DataSlice *problem, VertexId /*e_id*/ = 0,
                                                         VertexId /*e_id_in*/ = 0)
     {
-        const bool below = problem->d_labels[d_id] == problem->iteration + 1;
-        const VertexId from = below ? d_id : s_id;
-        const Value term = (static_cast<Value>(1) + problem->d_deltas[from]) / problem->d_sigmas[from];
-        return below ? problem->d_sigmas[s_id] * term : static_cast<Value>(0);
+        static_assert(sizeof(Value) == 4, "32-bit dependencies");
+        const int2 p = problem->d_packed[d_id];
+        const bool below = p.x == problem->iteration + 1;
+        return below ? problem->d_sigmas[s_id] * __int_as_float(p.y) : static_cast<Value>(0);
     }
     static __device__ __forceinline__ bool CondFilter(VertexId node, DataSlice *, Value = 0, SizeT = 0) { return node != -1; }
     static __device__ __forceinline__ void ApplyFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) {}

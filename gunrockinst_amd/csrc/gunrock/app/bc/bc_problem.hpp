@@ -48,6 +48,9 @@ struct BCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         VertexId *d_labels = nullptr;   // BFS depth from the source, -1 unreached
         Value *d_sigmas = nullptr;      // number of shortest paths from the source
         Value *d_deltas = nullptr;      // dependency of the source on the vertex
+        // backward phase: (label, (1 + delta) / sigma) side by side, so that an edge into the level below costs ONE 8-byte gather
+        // (the label test and the dependency term come with the same sector) instead of three 4-byte gathers from three arrays
+        int2 *d_packed = nullptr;
         Value *d_bc_values = nullptr;   // accumulated over sources
         Value *d_ebc_values = nullptr;  // per edge, stays 0 (see header)
         VertexId src_node = -1;
@@ -65,6 +68,7 @@ struct BCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                 if (ds->d_labels) hipFree(ds->d_labels);
                 if (ds->d_sigmas) hipFree(ds->d_sigmas);
                 if (ds->d_deltas) hipFree(ds->d_deltas);
+                if (ds->d_packed) hipFree(ds->d_packed);
                 if (ds->d_bc_values) hipFree(ds->d_bc_values);
                 if (ds->d_ebc_values) hipFree(ds->d_ebc_values);
                 delete ds;
@@ -84,6 +88,7 @@ struct BCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         GR_CHECK(hipMalloc(&ds->d_labels, sizeof(VertexId) * n), "BCProblem hipMalloc d_labels failed");
         GR_CHECK(hipMalloc(&ds->d_sigmas, sizeof(Value) * n), "BCProblem hipMalloc d_sigmas failed");
         GR_CHECK(hipMalloc(&ds->d_deltas, sizeof(Value) * n), "BCProblem hipMalloc d_deltas failed");
+        GR_CHECK(hipMalloc(&ds->d_packed, sizeof(int2) * n), "BCProblem hipMalloc d_packed failed");
         GR_CHECK(hipMalloc(&ds->d_bc_values, sizeof(Value) * n), "BCProblem hipMalloc d_bc_values failed");
         GR_CHECK(hipMalloc(&ds->d_ebc_values, sizeof(Value) * m), "BCProblem hipMalloc d_ebc_values failed");
         GR_CHECK(hipMemset(ds->d_bc_values, 0, sizeof(Value) * n), "BCProblem hipMemset failed");
