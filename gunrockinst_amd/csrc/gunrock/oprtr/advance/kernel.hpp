@@ -14,8 +14,9 @@
 //     when one R-MAT hub owns a million slots -- rows are split across tiles and workgroups, like
 //     RelaxPartitionedEdges2's per-slot search, edge_map_partitioned/kernel.cuh:369-392);
 //   * per tile the covering frontier slice (degree prefix, row start, vertex id) is staged in LDS with
-//     coalesced loads; each lane binary-searches the LDS prefix for its slot's owner, so consecutive
-//     lanes read consecutive column_indices entries (256 B per wave-instruction);
+//     coalesced loads; every staged entry marks the slot where its row begins and an inclusive max-scan
+//     over the marks on the DPP path gives each slot its owner (ExpandTiles below; no search per slot), so
+//     consecutive lanes read consecutive column_indices entries (256 B per wave-instruction);
 //   * accepted destinations go through FrontierWriter (LDS staging, one packed global atomic per flush).
 #pragma once
 
