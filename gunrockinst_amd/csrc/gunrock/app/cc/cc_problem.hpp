@@ -123,7 +123,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         const size_t m = static_cast<size_t>(this->edges > 0 ? this->edges : 1);
         GR_CHECK(hipMalloc(&ds->d_component_ids, sizeof(VertexId) * n), "CCProblem hipMalloc d_component_ids failed");
         GR_CHECK(hipMalloc(&ds->d_masks, sizeof(int) * n), "CCProblem hipMalloc d_masks failed");
-        GR_CHECK(hipMalloc(&ds->d_marks, m), "CCProblem hipMalloc d_marks failed");
+        GR_CHECK(hipMalloc(&ds->d_marks, m + 16), "CCProblem hipMalloc d_marks failed");  // (+16: the skipping sweep reads 16 flags at a time)
         GR_CHECK(hipMalloc(&ds->d_froms, sizeof(VertexId) * m), "CCProblem hipMalloc d_froms failed");
         GR_CHECK(hipMalloc(&ds->d_vertex_flag, sizeof(int) * 2), "CCProblem hipMalloc flags failed");
         ds->d_edge_flag = ds->d_vertex_flag + 1;
@@ -172,7 +172,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         hipStream_t stream = this->graph_slices[0]->stream;
         util::MemsetIdx(ds->d_component_ids, this->nodes, stream);
         util::Memset(ds->d_masks, 0, this->nodes, stream);
-        GR_CHECK(hipMemsetAsync(ds->d_marks, 0, static_cast<size_t>(this->edges > 0 ? this->edges : 1), stream),
+        GR_CHECK(hipMemsetAsync(ds->d_marks, 0, static_cast<size_t>(this->edges > 0 ? this->edges : 1) + 16, stream),
                  "CCProblem memset d_marks failed");
         GR_CHECK(hipMemsetAsync(ds->d_vertex_flag, 0, sizeof(int) * 2, stream), "CCProblem memset flags failed");
         GR_CHECK(hipStreamSynchronize(stream), "CCProblem Reset sync failed");
