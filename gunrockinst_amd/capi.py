@@ -121,6 +121,7 @@ _SIGNATURES = {
     "grx_cc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                C.POINTER(C.c_double)]),
     "grx_cc_mirrored": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "grx_cc_sweep_edges": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "grx_cc_extract": (C.c_int, [C.c_void_p, i32p, C.POINTER(C.c_uint)]),
     "grx_cc_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "grx_cc_destroy": (None, [C.c_void_p]),
@@ -492,8 +493,10 @@ class CcProblem:
         _check(lib().grx_cc_stats(self._h, C.byref(es), C.byref(vs), C.byref(l), C.byref(k)), "grx_cc_stats")
         mir = C.c_int()
         _check(lib().grx_cc_mirrored(self._h, C.byref(mir)), "grx_cc_mirrored")
+        se = C.c_longlong()
+        _check(lib().grx_cc_sweep_edges(self._h, C.byref(se)), "grx_cc_sweep_edges")
         return {"edge_sweeps": es.value, "vertex_sweeps": vs.value, "kernel_launches": l.value, "kernel_ms": k.value,
-                "mirrored": bool(mir.value)}
+                "mirrored": bool(mir.value), "sweep_edges": se.value}
 
     def extract(self):
         ids = np.empty(max(self.nodes, 1), dtype=np.int32)

@@ -64,7 +64,7 @@ class CCEnactor : public EnactorBase {
         const int grid = enactor_stats.filter_grid_size * 2;
         typename CCProblem::DataSlice *ds = problem->data_slices[0];
         hipStream_t stream = problem->graph_slices[0]->stream;
-        const SizeT n = problem->nodes, m = problem->edges;
+        const SizeT n = problem->nodes, m = problem->sweep_edges;  // (mirrored input: the from > to orientation only, cc_problem.hpp)
         edge_sweeps = vertex_sweeps = 0;
         if (n <= 0) return retval;
 

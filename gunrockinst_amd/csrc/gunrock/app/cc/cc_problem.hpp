@@ -14,9 +14,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include <gunrock/app/problem_base.hpp>
+#include <gunrock/graphio/device_csr.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
@@ -71,6 +73,63 @@ __global__ void MirrorCheckKernel(const SizeT *d_row_offsets, const VertexId *d_
     if (__ballot(missing) && util::LaneId() == 0) *d_missing = 1;
 }
 
+// ---- mirrored input: only the orientation with from > to ever hooks (HookInit, HookMax), so only it is materialised ----
+// d_count[v] = entries of row v below v (rows are sorted ascending: a binary search); d_count[nodes] = 0 closes the scan
+template <typename VertexId, typename SizeT>
+__global__ void LowerCountKernel(const SizeT *d_row_offsets, const VertexId *d_cols, long long nodes, unsigned *d_count)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v <= nodes; v += stride) {
+        unsigned below = 0;
+        if (v < nodes) {
+            const SizeT b = d_row_offsets[v];
+            SizeT lo = b, hi = d_row_offsets[v + 1];
+            while (lo < hi) {
+                const SizeT mid = lo + (hi - lo) / 2;
+                if (d_cols[mid] < static_cast<VertexId>(v)) lo = mid + 1; else hi = mid;
+            }
+            below = static_cast<unsigned>(lo - b);
+        }
+        d_count[v] = below;
+    }
+}
+// the (from, to) pairs with to < from, row by row (one wave per 64 rows; long rows by the whole wave)
+template <typename VertexId, typename SizeT>
+__global__ void LowerFillKernel(const SizeT *d_row_offsets, const VertexId *d_cols, const SizeT *d_low_offsets, long long nodes,
+                                VertexId *d_low_froms, VertexId *d_low_tos)
+{
+    const unsigned lane = util::LaneId();
+    const long long wave0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / util::kWaveSize;
+    const long long nwaves = static_cast<long long>(gridDim.x) * blockDim.x / util::kWaveSize;
+    const long long groups = (nodes + 63) / 64;
+    for (long long g = wave0; g < groups; g += nwaves) {
+        const long long v = g * 64 + lane;
+        SizeT src = 0, dst = 0, len = 0;
+        if (v < nodes) {
+            src = d_row_offsets[v];
+            dst = d_low_offsets[v];
+            len = d_low_offsets[v + 1] - dst;
+        }
+        const bool long_row = len > 16;
+        if (!long_row)
+            for (SizeT i = 0; i < len; ++i) {
+                d_low_froms[dst + i] = static_cast<VertexId>(v);
+                d_low_tos[dst + i] = d_cols[src + i];
+            }
+        unsigned long long todo = __ballot(long_row);
+        while (todo) {
+            const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+            const SizeT ls = __shfl(src, leader, util::kWaveSize), ld = __shfl(dst, leader, util::kWaveSize), ll = __shfl(len, leader, util::kWaveSize);
+            const VertexId lv = static_cast<VertexId>(g * 64 + leader);
+            for (SizeT i = static_cast<SizeT>(lane); i < ll; i += util::kWaveSize) {
+                d_low_froms[ld + i] = lv;
+                d_low_tos[ld + i] = d_cols[ls + i];
+            }
+            todo &= todo - 1;
+        }
+    }
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _USE_DOUBLE_BUFFER>
 struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     typedef ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> Base;
@@ -94,6 +153,10 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     DataSlice **data_slices = nullptr;
     unsigned int num_components = 0;
     int *h_flags = nullptr;  // pinned: [0] vertex flag, [1] edge flag
+    // edges the hooking sweeps run over: all of them, or -- mirrored input -- the from > to orientation only (AllocData)
+    _SizeT sweep_edges = 0;
+    bool compact_mirrored = true;      // policy (tests switch it off to run the parking path)
+    _VertexId *d_owned_tos = nullptr;  // the compact `to` array when the problem owns one (d_tos otherwise aliases the CSR's columns)
 
     ~CCProblem() override
     {
@@ -110,6 +173,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             delete[] data_slices;
         }
         if (h_flags) util::GRError(hipHostFree(h_flags), "CCProblem hipHostFree failed", __FILE__, __LINE__);
+        if (d_owned_tos) util::GRError(hipFree(d_owned_tos), "CCProblem hipFree failed", __FILE__, __LINE__);
     }
 
     hipError_t AllocData()
@@ -148,6 +212,43 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipStreamSynchronize(gs->stream), "MirrorCheckKernel failed");
             ds->symmetric = missing ? 0 : 1;
         }
+        sweep_edges = this->edges;
+        if (const char *env = std::getenv("GUNROCK_CC_COMPACT")) compact_mirrored = env[0] != '0';  // (tests: "0" keeps both orientations)
+        if (ds->symmetric && this->edges > 0 && compact_mirrored) {
+            // Mirrored input: the orientation from < to would be parked at first sight by every hooking sweep (its mirror does the very
+            // same hook).  Materialise only the from > to pairs -- half the edge stream for HookInit and for every HookMax sweep
+            // (the reference sweeps both orientations of its COO, cc_enactor.cuh:407-424, 560-600).
+            const long long n1 = static_cast<long long>(this->nodes) + 1;
+            unsigned *d_count = nullptr;
+            unsigned long long *d_sums = nullptr;
+            SizeT *d_low_offsets = nullptr;
+            GR_CHECK(hipMalloc(&d_count, sizeof(unsigned) * static_cast<size_t>(n1)), "CCProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_low_offsets, sizeof(SizeT) * static_cast<size_t>(n1)), "CCProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * static_cast<size_t>(graphio::ScanScratchWords(n1))), "CCProblem hipMalloc failed");
+            hipLaunchKernelGGL((LowerCountKernel<VertexId, SizeT>), dim3(2048), dim3(256), 0, gs->stream, gs->d_row_offsets, ds->d_tos,
+                               static_cast<long long>(this->nodes), d_count);
+            GR_CHECK(hipGetLastError(), "LowerCountKernel launch failed");
+            GR_CHECK(graphio::DeviceExclusiveScan<SizeT>(d_count, d_low_offsets, n1, d_sums, gs->stream), "CCProblem lower-offset scan failed");
+            SizeT low_edges = 0;
+            GR_CHECK(hipMemcpyAsync(&low_edges, d_low_offsets + this->nodes, sizeof(SizeT), hipMemcpyDeviceToHost, gs->stream), "CCProblem read failed");
+            GR_CHECK(hipStreamSynchronize(gs->stream), "CCProblem lower-offset scan failed");
+            const size_t lm = static_cast<size_t>(low_edges > 0 ? low_edges : 1);
+            VertexId *d_low_froms = nullptr, *d_low_tos = nullptr;
+            GR_CHECK(hipMalloc(&d_low_froms, sizeof(VertexId) * lm), "CCProblem hipMalloc failed");
+            GR_CHECK(hipMalloc(&d_low_tos, sizeof(VertexId) * lm), "CCProblem hipMalloc failed");
+            hipLaunchKernelGGL((LowerFillKernel<VertexId, SizeT>), dim3(2048), dim3(256), 0, gs->stream, gs->d_row_offsets, ds->d_tos, d_low_offsets,
+                               static_cast<long long>(this->nodes), d_low_froms, d_low_tos);
+            GR_CHECK(hipGetLastError(), "LowerFillKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(gs->stream), "LowerFillKernel failed");
+            GR_CHECK(hipFree(ds->d_froms), "CCProblem hipFree failed");  // the full expansion is not needed any more
+            ds->d_froms = d_low_froms;
+            ds->d_tos = d_low_tos;
+            d_owned_tos = d_low_tos;
+            sweep_edges = low_edges;
+            GR_CHECK(hipFree(d_count), "CCProblem hipFree failed");
+            GR_CHECK(hipFree(d_low_offsets), "CCProblem hipFree failed");
+            GR_CHECK(hipFree(d_sums), "CCProblem hipFree failed");
+        }
         return retval;
     }
 
@@ -172,7 +273,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         hipStream_t stream = this->graph_slices[0]->stream;
         util::MemsetIdx(ds->d_component_ids, this->nodes, stream);
         util::Memset(ds->d_masks, 0, this->nodes, stream);
-        GR_CHECK(hipMemsetAsync(ds->d_marks, 0, static_cast<size_t>(this->edges > 0 ? this->edges : 1) + 16, stream),
+        GR_CHECK(hipMemsetAsync(ds->d_marks, 0, static_cast<size_t>(sweep_edges > 0 ? sweep_edges : 1) + 16, stream),
                  "CCProblem memset d_marks failed");
         GR_CHECK(hipMemsetAsync(ds->d_vertex_flag, 0, sizeof(int) * 2, stream), "CCProblem memset flags failed");
         GR_CHECK(hipStreamSynchronize(stream), "CCProblem Reset sync failed");

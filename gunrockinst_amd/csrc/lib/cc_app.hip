@@ -30,6 +30,7 @@ struct CcRunner {
     virtual hipError_t Extract(int *ids, unsigned *num_components) = 0;
     virtual int *DeviceIds() = 0;
     virtual int Mirrored() = 0;
+    virtual long long SweepEdges() = 0;
 };
 
 template <bool INSTR>
@@ -82,6 +83,7 @@ struct CcRunnerT : CcRunner {
     }
     int *DeviceIds() override { return problem.data_slices ? problem.data_slices[0]->d_component_ids : nullptr; }
     int Mirrored() override { return problem.data_slices ? problem.data_slices[0]->symmetric : 0; }
+    long long SweepEdges() override { return problem.sweep_edges; }
 };
 
 }  // namespace
@@ -145,6 +147,13 @@ int grx_cc_mirrored(grx_cc *p, int *mirrored)
 {
     if (!p || !mirrored) return -1;
     *mirrored = p->runner->Mirrored();
+    return 0;
+}
+
+int grx_cc_sweep_edges(grx_cc *p, long long *edges)
+{
+    if (!p || !edges) return -1;
+    *edges = p->runner->SweepEdges();
     return 0;
 }
 

@@ -193,6 +193,9 @@ int grx_cc_stats(grx_cc *p, long long *edge_sweeps, long long *vertex_sweeps, lo
 /* *mirrored = 1 when Init found every edge (f, t), f < t, mirrored by (t, f): the hooking sweeps then park that orientation on first
  * sight (its mirror performs the identical root comparison), i.e. from the second edge sweep on half of the edges are skipped */
 int grx_cc_mirrored(grx_cc *p, int *mirrored);
+/* edges the hooking sweeps run over: all of them, or -- mirrored input -- only the from > to orientation of every edge, which the
+ * problem materialises once at init (the other orientation performs the identical hooks) */
+int grx_cc_sweep_edges(grx_cc *p, long long *edges);
 int grx_cc_extract(grx_cc *p, int *h_component_ids, unsigned *num_components);
 int grx_cc_device_results(grx_cc *p, int **d_component_ids);
 void grx_cc_destroy(grx_cc *p);

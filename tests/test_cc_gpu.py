@@ -102,3 +102,14 @@ def test_instrumented_and_rerun():
     st = p.stats()
     assert st["kernel_launches"] == st["edge_sweeps"] + st["vertex_sweeps"] and 0 < st["kernel_ms"] <= ms
     p.close()
+
+
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_mirrored_input_with_and_without_the_compact_edge_list(compact, monkeypatch):
+    # mirrored graphs materialise only the from > to orientation of every edge for the hooking sweeps (cc_problem.hpp); with
+    # GUNROCK_CC_COMPACT=0 both orientations stay and the from < to one is parked at first sight.  Same labels either way, also for
+    # graphs with hubs, isolated vertices, many small components, and for a directed graph (never compacted).
+    monkeypatch.setenv("GUNROCK_CC_COMPACT", compact)
+    for g in (o.rmat_seeded(10, 4 << 10), o.rmat_seeded(16, 8 << 16), o.rmat_seeded(18, 2 << 18), o.rmat_seeded(15, 8 << 15, undirected=False)):
+        st = _check(g)
+        assert st["edge_sweeps"] >= 1
