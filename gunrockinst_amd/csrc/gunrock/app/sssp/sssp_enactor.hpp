@@ -155,9 +155,14 @@ class SSSPEnactor : public EnactorBase {
                                 args, *ds, max_grid_size, stream, oprtr::advance::V2V)))
                     break;
                 if (INSTRUMENT && (retval = InstrumentEnd(stream))) break;
-                if ((retval = read_tails())) break;
-                if (INSTRUMENT) InstrumentCollect(queue_length, queue_edges, 0);
-                const unsigned candidates = util::TailCount(h_tail[0]);
+                // The split follows the advance on the stream: it reads the candidate count from the advance's device tail, so the
+                // host makes ONE round trip per iteration, not two (the instrumented enactor keeps the two, for per-kernel times).
+                unsigned candidates = static_cast<unsigned>(problem->candidate_capacity);  // (upper bound: sizes the split's grid)
+                if (INSTRUMENT) {
+                    if ((retval = read_tails())) break;
+                    InstrumentCollect(queue_length, queue_edges, 0);
+                    candidates = util::TailCount(h_tail[0]);
+                }
 
                 // ---- split candidates into near (next frontier) and far (parked) ----
                 queue_length = 0;
@@ -168,6 +173,7 @@ class SSSPEnactor : public EnactorBase {
                     b.d_in = problem->d_candidates;
                     b.d_in_dist = nullptr;
                     b.num_elements = static_cast<SizeT>(candidates);
+                    b.d_num_elements = INSTRUMENT ? nullptr : d_tail + 0;
                     b.level = level;
                     b.tag = ++tag;
                     b.near = gs->frontier_queues[selector ^ 1];

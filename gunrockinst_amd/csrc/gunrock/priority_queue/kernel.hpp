@@ -29,6 +29,9 @@ struct BisectArgs {
     const VertexId *d_in;        // queue to split
     const unsigned *d_in_dist;   // distance at parking time (far pile input) or NULL (advance output)
     SizeT num_elements;
+    // when set: the element count is the low word of this packed device tail (the advance that produced d_in wrote it; the
+    // split then follows the advance on the stream without a host round trip in between) and num_elements is ignored
+    const unsigned long long *d_num_elements = nullptr;
     unsigned level;              // buckets <= level are near
     int tag;                     // unique per call, for de-duplication
     util::Frontier<VertexId, SizeT> near;   // output frontier
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(THREADS) void BisectKernel(BisectArgs<typename Prob
     __syncthreads();
 
     unsigned far_min = 0xFFFFFFFFu;
-    const long long tiles = (static_cast<long long>(a.num_elements) + TILE - 1) / TILE;
+    const long long num_elements = a.d_num_elements ? static_cast<long long>(util::TailCount(*a.d_num_elements)) : static_cast<long long>(a.num_elements);
+    const long long tiles = (num_elements + TILE - 1) / TILE;
     for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int pending = Writer::Count(s_writer);
         __syncthreads();
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(THREADS) void BisectKernel(BisectArgs<typename Prob
         for (int k = 0; k < ITEMS; ++k) {
             const long long i = tile * TILE + k * THREADS + threadIdx.x;
             v[k] = -1;
-            if (i < a.num_elements) v[k] = a.d_in[i];
+            if (i < num_elements) v[k] = a.d_in[i];
         }
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
@@ -132,10 +136,12 @@ template <int THREADS, int ITEMS, typename ProblemData, typename Functor>
 hipError_t Bisect(const BisectArgs<typename ProblemData::VertexId, typename ProblemData::SizeT> &args,
                   const typename ProblemData::DataSlice &slice, int max_grid_size, hipStream_t stream)
 {
-    if (args.num_elements <= 0) return hipSuccess;
+    if (!args.d_num_elements && args.num_elements <= 0) return hipSuccess;
+    // (count on the device: num_elements is then the caller's upper bound for sizing the grid)
     const long long tiles = (static_cast<long long>(args.num_elements) + THREADS * ITEMS - 1) / (THREADS * ITEMS);
-    hipLaunchKernelGGL((BisectKernel<THREADS, ITEMS, ProblemData, Functor>),
-                       dim3(static_cast<unsigned>(tiles < max_grid_size ? tiles : max_grid_size)), dim3(THREADS), 0, stream, args,
+    long long grid = tiles < max_grid_size ? tiles : max_grid_size;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((BisectKernel<THREADS, ITEMS, ProblemData, Functor>), dim3(static_cast<unsigned>(grid)), dim3(THREADS), 0, stream, args,
                        slice);
     return util::GRError("priority_queue::BisectKernel launch failed", __FILE__, __LINE__);
 }
