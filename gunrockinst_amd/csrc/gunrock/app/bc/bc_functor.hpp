@@ -44,7 +44,8 @@ struct ForwardFunctor {
     // atomicCAS of every surviving edge of a tile is issued before any of them is examined (CondEdge alone waits for its own CAS
     // and then loads sigma[s] inside the per-edge branch: two exposed round trips per edge) ----
     struct EdgeState {
-        Value sigma_s;  // path count of the source, as staged with the frontier entry
+        Value sigma_s;        // path count of the source, as staged with the frontier entry
+        VertexId label_seen;  // the destination's label as the screen read it
     };
     static __device__ __forceinline__ unsigned SourceData(VertexId s_id, DataSlice *problem)
     {
@@ -55,11 +56,18 @@ struct ForwardFunctor {
                                                       unsigned source_data, EdgeState &state)
     {
         state.sigma_s = __uint_as_float(source_data);
-        return ScreenEdge(s_id, d_id, problem, e_id, e_id_in);
+        const VertexId label = problem->d_labels[d_id];  // (a stale -1 only costs the atomicCAS below)
+        state.label_seen = label;
+        return label == -1 || label == problem->iteration + 1;
     }
-    static __device__ __forceinline__ VertexId IssueEdge(VertexId, VertexId d_id, DataSlice *problem, VertexId, VertexId, unsigned, EdgeState &)
+    // Round 3: a destination the screen already saw on THIS level's label needs no claim -- some earlier edge discovered it -- only
+    // the path-count add.  On a scale-free level a vertex is reached over a dozen edges: all but the first few claims were
+    // memory-side atomics that changed nothing (they retire at ~27 G/s whether they change anything or not).
+    static __device__ __forceinline__ VertexId IssueEdge(VertexId, VertexId d_id, DataSlice *problem, VertexId, VertexId, unsigned, EdgeState &state)
     {
-        return atomicCAS(problem->d_labels + d_id, static_cast<VertexId>(-1), static_cast<VertexId>(problem->iteration + 1));
+        const VertexId level = static_cast<VertexId>(problem->iteration + 1);
+        if (state.label_seen == level) return level;
+        return atomicCAS(problem->d_labels + d_id, static_cast<VertexId>(-1), level);
     }
     static __device__ __forceinline__ bool ResolveEdge(VertexId old, VertexId, VertexId d_id, DataSlice *problem, VertexId, VertexId, EdgeState &state)
     {
