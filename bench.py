@@ -482,7 +482,7 @@ def _compact(d, extra=()):
     out["workload"] = d["config"]["workload"]
     r = d.get("roofline") or {}
     out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "kernel", "kernel_avg_launch_ms",
-                                             "alg_bytes", "note", "I_h", "I_j", "parked_edge_fraction") if k in r}
+                                             "alg_bytes", "note", "I_h", "I_j", "parked_edge_fraction", "frac_own_sweeps", "this_run") if k in r}
     return out
 
 
@@ -690,10 +690,12 @@ def bench_cc(args, torch, ga, devgraph, device_index):
                          "mirrored": st.get("mirrored"),
                          "parked_edge_fraction": round(1.0 - st.get("sweep_edges", m) / float(m), 4) if m else 0.0,
                          "frac_own_sweeps": round(own_balg / t_enact / 8e12, 5),
-                         "note": "B_alg = I_h*9m + I_j*8n (the REFERENCE schedule over both orientations of every edge) over Enact time.  On a mirrored "
-                                 "graph this implementation materialises only the from > to orientation (the other one performs the identical hooks): "
-                                 "its sweeps run over sweep_edges = m * (1 - parked_edge_fraction) edges, so its physical edge traffic is about half "
-                                 "of what the numerator charges; frac_own_sweeps prices this run's own sweeps instead"},
+                         "note": "frac = B_alg / Enact time / 8 TB/s with B_alg = I_h*9m + I_j*8n of the REFERENCE schedule (I_h hooking and I_j jumping "
+                                 "sweeps over both orientations of every edge, from the oracle's simulation of cc_enactor.cuh:165-873), as SURVEY 8(d) "
+                                 "defines it.  It can exceed 1: this implementation does LESS than that schedule -- on a mirrored graph it materialises only "
+                                 "the from > to orientation (the other one performs the identical hooks: sweep_edges = m * (1 - parked_edge_fraction)) and "
+                                 "its opening move hooks every vertex under its SMALLEST lower neighbour, after which fewer sweeps are needed (this_run).  "
+                                 "frac_own_sweeps prices this run's own sweeps over its own edge list: that is the bandwidth figure"},
             "cpu_baseline": cpu}
 
 

@@ -100,7 +100,13 @@ class CCEnactor : public EnactorBase {
             return rc;
         };
 
-        if (m > 0) GR_CC_SWEEP(HookInit, m, 1);
+        if (m > 0) {
+            if (slice.d_first_lower) {  // mirrored input, compact layout: the opening hooks as a vertex sweep (cc_functor.hpp)
+                typedef HookInitRowFunctor<VertexId, SizeT, Value, CCProblem> HookInitRow;
+                GR_CC_SWEEP(HookInitRow, n, 1);
+            } else
+                GR_CC_SWEEP(HookInit, m, 1);
+        }
         for (;;) {  // first pointer-jumping round (cc_enactor.cuh:442-493)
             GR_CC_SWEEP(PtrJump, n, 0);
             if ((retval = poll())) return retval;

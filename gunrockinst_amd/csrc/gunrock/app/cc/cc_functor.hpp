@@ -59,6 +59,20 @@ struct HookInitFunctor {
     }
 };
 
+// The same opening move as a VERTEX sweep, for the compact layout of a mirrored input (cc_problem.hpp): every from > to edge of a
+// row writes parent[from] = to and the last store wins, i.e. "some neighbour below me becomes my parent" -- the row's first
+// entry, precomputed per vertex, is one of them.  n 4-byte reads instead of a pass over the edge list.
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookInitRowFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        const VertexId below = problem->d_first_lower[node];
+        if (below < node) StoreFresh(problem->d_component_ids + node, below);
+    }
+};
+
 // hook the larger root under the smaller one; an edge whose ends share a root is marked done -- cc_functor.cuh:172-216
 template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
 struct HookMaxFunctor {

@@ -130,6 +130,16 @@ __global__ void LowerFillKernel(const SizeT *d_row_offsets, const VertexId *d_co
     }
 }
 
+template <typename VertexId, typename SizeT>
+__global__ void FirstLowerKernel(const SizeT *d_low_offsets, const VertexId *d_low_tos, long long nodes, VertexId *d_first)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; v < nodes; v += stride) {
+        const SizeT b = d_low_offsets[v];
+        d_first[v] = d_low_offsets[v + 1] > b ? d_low_tos[b] : static_cast<VertexId>(v);
+    }
+}
+
 template <typename _VertexId, typename _SizeT, typename _Value, bool _USE_DOUBLE_BUFFER>
 struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     typedef ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> Base;
@@ -146,6 +156,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         VertexId *d_froms = nullptr;          // per edge: source vertex
         const VertexId *d_tos = nullptr;      // per edge: destination vertex (= CSR column_indices)
         int symmetric = 0;                    // every edge has its mirror: hooking sweeps need one orientation only
+        const VertexId *d_first_lower = nullptr;  // compact (mirrored) layout: per vertex its smallest neighbour below it, or itself
         int *d_vertex_flag = nullptr;         // cleared by a pointer-jump sweep that changed something
         int *d_edge_flag = nullptr;           // cleared by a hook sweep that hooked something
     };
@@ -156,6 +167,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // edges the hooking sweeps run over: all of them, or -- mirrored input -- the from > to orientation only (AllocData)
     _SizeT sweep_edges = 0;
     bool compact_mirrored = true;      // policy (tests switch it off to run the parking path)
+    _VertexId *d_owned_first = nullptr;
     _VertexId *d_owned_tos = nullptr;  // the compact `to` array when the problem owns one (d_tos otherwise aliases the CSR's columns)
 
     ~CCProblem() override
@@ -174,6 +186,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         }
         if (h_flags) util::GRError(hipHostFree(h_flags), "CCProblem hipHostFree failed", __FILE__, __LINE__);
         if (d_owned_tos) util::GRError(hipFree(d_owned_tos), "CCProblem hipFree failed", __FILE__, __LINE__);
+        if (d_owned_first) util::GRError(hipFree(d_owned_first), "CCProblem hipFree failed", __FILE__, __LINE__);
     }
 
     hipError_t AllocData()
@@ -240,6 +253,15 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
                                static_cast<long long>(this->nodes), d_low_froms, d_low_tos);
             GR_CHECK(hipGetLastError(), "LowerFillKernel launch failed");
             GR_CHECK(hipStreamSynchronize(gs->stream), "LowerFillKernel failed");
+            // ... and per vertex its smallest neighbour below it (the first entry of its compact row), which is all HookInit needs
+            VertexId *d_first = nullptr;
+            GR_CHECK(hipMalloc(&d_first, sizeof(VertexId) * static_cast<size_t>(this->nodes > 0 ? this->nodes : 1)), "CCProblem hipMalloc failed");
+            hipLaunchKernelGGL((FirstLowerKernel<VertexId, SizeT>), dim3(2048), dim3(256), 0, gs->stream, d_low_offsets, d_low_tos,
+                               static_cast<long long>(this->nodes), d_first);
+            GR_CHECK(hipGetLastError(), "FirstLowerKernel launch failed");
+            GR_CHECK(hipStreamSynchronize(gs->stream), "FirstLowerKernel failed");
+            ds->d_first_lower = d_first;
+            d_owned_first = d_first;
             GR_CHECK(hipFree(ds->d_froms), "CCProblem hipFree failed");  // the full expansion is not needed any more
             ds->d_froms = d_low_froms;
             ds->d_tos = d_low_tos;
