@@ -158,8 +158,9 @@ struct WorkProgress {
     // (BFSProblem) keeps a pointer to them across searches; it asks here whether the enactor is still alive before using it.
     static std::set<const WorkProgress *> &Live()
     {
-        static std::set<const WorkProgress *> live;
-        return live;
+        static std::set<const WorkProgress *> *live = new std::set<const WorkProgress *>();  // (never destroyed: an enactor may be
+                                                                                             //  released during static destruction)
+        return *live;
     }
     static bool IsLive(const WorkProgress *p) { return p && Live().count(p) != 0; }
 
