@@ -694,8 +694,10 @@ def bench_cc(args, torch, ga, devgraph, device_index):
                                  "sweeps over both orientations of every edge, from the oracle's simulation of cc_enactor.cuh:165-873), as SURVEY 8(d) "
                                  "defines it.  It can exceed 1: this implementation does LESS than that schedule -- on a mirrored graph it materialises only "
                                  "the from > to orientation (the other one performs the identical hooks: sweep_edges = m * (1 - parked_edge_fraction)) and "
-                                 "its opening move hooks every vertex under its SMALLEST lower neighbour, after which fewer sweeps are needed (this_run).  "
-                                 "frac_own_sweeps prices this run's own sweeps over its own edge list: that is the bandwidth figure"},
+                                 "its opening move hooks every vertex under its SMALLEST lower neighbour, and after one neighbour round the sampled giant "
+                                 "component sits out of the hooking sweeps, which run one lane per vertex over CSR rows (this_run counts them, the opening "
+                                 "and the neighbour round with the vertex sweeps; DESIGN 3.4).  frac_own_sweeps prices this run's own sweeps (9 B per edge "
+                                 "of an edge-form sweep, 8 B per vertex of a vertex sweep): that is the bandwidth figure"},
             "cpu_baseline": cpu}
 
 

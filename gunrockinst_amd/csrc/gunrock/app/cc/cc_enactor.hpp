@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <gunrock/app/cc/cc_functor.hpp>
 #include <gunrock/app/cc/cc_problem.hpp>
@@ -103,7 +104,7 @@ class CCEnactor : public EnactorBase {
         if (m > 0) {
             if (slice.d_first_lower) {  // mirrored input, compact layout: the opening hooks as a vertex sweep (cc_functor.hpp)
                 typedef HookInitRowFunctor<VertexId, SizeT, Value, CCProblem> HookInitRow;
-                GR_CC_SWEEP(HookInitRow, n, 1);
+                GR_CC_SWEEP(HookInitRow, n, 0);  // (a vertex sweep: n parents written from a per-vertex array, no edge is read)
             } else
                 GR_CC_SWEEP(HookInit, m, 1);
         }
@@ -115,7 +116,70 @@ class CCEnactor : public EnactorBase {
         }
         GR_CC_SWEEP(UpdateMask, n, 0);
 
+        // ---- row form of the hooking sweeps (cc_functor.hpp HookMaxRowFunctor): mirrored input whose sampled giant component
+        //      holds at least a quarter of the samples.  It starts AFTER the first edge-form sweep and its jumps: before that the
+        //      giant component is still a forest of many trees (measured: started at the first sweep, a vertex with a long row
+        //      outside the sampled tree sent the run back to the edge form at once, 1.68 -> 1.81 ms). ----
+        bool row_form = false;
+        const bool row_form_wanted = m > 0 && slice.d_first_lower && problem->row_form;
+        VertexId *d_giant = reinterpret_cast<VertexId *>(work_progress.d_tail + 4);  // slots 4, 5: mirrored by every read-back
+        if (row_form_wanted) {
+            slice.d_giant = d_giant;
+            if (const char *env = std::getenv("GUNROCK_CC_ROW_LIMIT")) slice.row_form_limit = static_cast<SizeT>(std::atoi(env));
+        }
+        auto pick_giant = [&]() -> hipError_t {  // (queued in front of a read-back the schedule makes anyway)
+            hipLaunchKernelGGL((PickGiantKernel<VertexId>), dim3(1), dim3(kGiantSamples), 0, stream, ds->d_component_ids, static_cast<long long>(n), d_giant);
+            return util::GRError("PickGiantKernel launch failed", __FILE__, __LINE__);
+        };
+
+        // ---- neighbour rounds (cc_functor.hpp HookNeighbourFunctor): HookMax over ONE edge per vertex, then the jumps of a
+        //      hooking round.  The opening already took every vertex's smallest lower neighbour; round r takes the (r + 1)-th.
+        //      After them the giant is sampled, and if it dominates, the first FULL hooking sweep is already in row form. ----
+        if (row_form_wanted && slice.d_low_offsets) {
+            typedef HookNeighbourFunctor<VertexId, SizeT, Value, CCProblem> HookNeighbour;
+            for (int r = 1; r <= problem->neighbour_rounds; ++r) {
+                slice.neighbour_round = r;
+                GR_CC_SWEEP(HookNeighbour, n, 0);
+                for (;;) {
+                    GR_CC_SWEEP(PtrJumpMask, n, 0);
+                    if ((retval = poll())) return retval;
+                    ++enactor_stats.iteration;
+                    if (vertex_stable) break;
+                }
+                GR_CC_SWEEP(PtrJumpUnmask, n, 0);
+                GR_CC_SWEEP(UpdateMask, n, 0);
+            }
+            if (problem->neighbour_rounds > 0) {
+                if ((retval = pick_giant())) return retval;
+                if ((retval = poll())) return retval;
+                const long long samples = n >= kGiantSamples ? kGiantSamples : n;
+                row_form = static_cast<long long>(work_progress.h_tail[4] >> 32) * 4 >= samples;
+            }
+        }
+
+        bool hooks_pending = false;  // a row-form sweep of this round hooked something before the edge form took over
         while (m > 0) {  // cc_enactor.cuh:524-862
+            if (row_form) {
+                typedef HookMaxRowFunctor<VertexId, SizeT, Value, CCProblem> HookMaxRow;
+                GR_CC_SWEEP(HookMaxRow, n, 0);  // (counted with the vertex sweeps: it reads the parents, not the edge list)
+                if ((retval = poll())) return retval;
+                const bool rows_hooked = !edge_stable;
+                const bool long_row = (work_progress.h_tail[5] & 0xFFFFFFFFull) != 0;
+                if (!long_row) {
+                    ++enactor_stats.iteration;
+                    if (!rows_hooked) break;
+                    for (;;) {
+                        GR_CC_SWEEP(PtrJumpMask, n, 0);
+                        if ((retval = poll())) return retval;
+                        if (vertex_stable) break;
+                    }
+                    GR_CC_SWEEP(PtrJumpUnmask, n, 0);
+                    GR_CC_SWEEP(UpdateMask, n, 0);
+                    continue;
+                }
+                row_form = false;  // a vertex outside the giant has a row too long for one lane: the edge form from here on
+                hooks_pending = rows_hooked;
+            }
             // From the third hooking sweep on nearly every edge is marked done, and the sweep is a scan of the flags: it tests 16 of
             // them per lane (filter::LaunchApplySkip: 272 -> 50-66 us at scale-24).  The first two sweeps still touch most edges, and
             // there one edge per lane keeps the endpoint loads coalesced (16 consecutive edges per lane: 1.4 -> 7.8 ms for the first sweep;
@@ -135,7 +199,8 @@ class CCEnactor : public EnactorBase {
             enactor_stats.total_queued += m;
             if ((retval = poll())) return retval;
             ++enactor_stats.iteration;
-            if (edge_stable) break;  // no edge hooked anything: done
+            if (edge_stable && !hooks_pending) break;  // no edge hooked anything: done
+            hooks_pending = false;
             for (;;) {
                 GR_CC_SWEEP(PtrJumpMask, n, 0);
                 if ((retval = poll())) return retval;
@@ -143,6 +208,13 @@ class CCEnactor : public EnactorBase {
             }
             GR_CC_SWEEP(PtrJumpUnmask, n, 0);
             GR_CC_SWEEP(UpdateMask, n, 0);
+            if (row_form_wanted && hook_sweeps == 1) {  // the first edge-form round is over: does one component dominate now?
+                if ((retval = pick_giant())) return retval;
+                if ((retval = poll())) return retval;
+                const long long samples = n >= kGiantSamples ? kGiantSamples : n;
+                const long long held = static_cast<long long>(work_progress.h_tail[4] >> 32);
+                row_form = held * 4 >= samples;
+            }
         }
 #undef GR_CC_SWEEP
         return retval;

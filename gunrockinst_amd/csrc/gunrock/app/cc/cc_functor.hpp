@@ -73,6 +73,68 @@ struct HookInitRowFunctor {
     }
 };
 
+// A NEIGHBOUR ROUND (Afforest's first phase inside this schedule): HookMax applied to ONE edge per vertex -- the edge to its
+// (neighbour_round + 1)-th smallest lower neighbour.  n gathers instead of one per edge; after a couple of such rounds (each followed
+// by the pointer jumps) a scale-free graph's giant component is essentially one tree, and the row-form sweeps below let everything
+// rooted at it sit out.
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookNeighbourFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        const SizeT at = problem->d_low_offsets[node] + problem->neighbour_round;
+        if (at >= problem->d_low_offsets[node + 1]) return;
+        const VertexId pf = LoadFresh(problem->d_component_ids + node);
+        const VertexId pt = LoadFresh(problem->d_component_ids + problem->d_tos[at]);
+        if (pf != pt) {
+            const VertexId hi = pf > pt ? pf : pt, lo = pf > pt ? pt : pf;
+            StoreFresh(problem->d_component_ids + hi, lo);
+            StoreFresh(problem->d_edge_flag, 0);
+        }
+    }
+};
+
+// HookMax in ROW form, for a mirrored input with a dominant component (cc_problem.hpp PickGiantKernel; the idea of Afforest's
+// "skip the largest intermediate component", Sutton et al., inside the reference's hook / jump schedule): a vertex whose root is
+// the giant's root does nothing at all -- an edge between two such vertices needs no hook, and an edge to a vertex OUTSIDE the
+// giant is seen from that vertex's own row, because every edge has its mirror.  Only the few vertices outside it walk their
+// rows (both orientations) and hook exactly as HookMax does.  A scale-24 R-MAT sweep then reads 64 MB of parents instead of
+// gathering a parent per edge (1.08 ms -> ~0.04 ms).  A row longer than row_form_limit raises word [2]: the enactor runs the
+// edge form for that round as well (correct for any graph; the row form is only ever a shortcut).
+template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
+struct HookMaxRowFunctor {
+    typedef typename ProblemData::DataSlice DataSlice;
+    static __device__ __forceinline__ bool CondFilter(VertexId, DataSlice *, Value = 0, SizeT = 0) { return true; }
+    static __device__ __forceinline__ void ApplyFilter(VertexId node, DataSlice *problem, Value = 0, SizeT = 0)
+    {
+        const VertexId pf = LoadFresh(problem->d_component_ids + node);
+        VertexId giant = problem->d_giant[0];
+        if (giant >= 0) {  // the giant's root may itself have been hooked under a smaller root since it was picked: follow it
+#pragma unroll 1
+            for (int hop = 0; hop < 16; ++hop) {
+                const VertexId up = LoadFresh(problem->d_component_ids + giant);
+                if (up == giant) break;
+                giant = up;
+            }
+            if (pf == giant) return;
+        }
+        const SizeT begin = problem->d_row_offsets[node], end = problem->d_row_offsets[node + 1];
+        if (end - begin > problem->row_form_limit) {
+            problem->d_giant[2] = 1;
+            return;
+        }
+        for (SizeT e = begin; e < end; ++e) {
+            const VertexId pt = LoadFresh(problem->d_component_ids + problem->d_columns[e]);
+            if (pt != pf) {
+                const VertexId hi = pf > pt ? pf : pt, lo = pf > pt ? pt : pf;
+                StoreFresh(problem->d_component_ids + hi, lo);
+                StoreFresh(problem->d_edge_flag, 0);
+            }
+        }
+    }
+};
+
 // hook the larger root under the smaller one; an edge whose ends share a root is marked done -- cc_functor.cuh:172-216
 template <typename VertexId, typename SizeT, typename Value, typename ProblemData>
 struct HookMaxFunctor {

@@ -130,6 +130,38 @@ __global__ void LowerFillKernel(const SizeT *d_row_offsets, const VertexId *d_co
     }
 }
 
+// The component most of a sample of vertices belongs to (one workgroup of kGiantSamples threads; the sweeps before it left every vertex
+// pointing at its root): d_giant[0] = that root, [1] = samples holding it, [2] = 0.  Isolated vertices are their own roots and
+// never form a majority, so on a graph without a big component [1] stays small and the caller keeps the edge-form sweeps.
+constexpr int kGiantSamples = 256;
+template <typename VertexId>
+__global__ __launch_bounds__(kGiantSamples) void PickGiantKernel(const VertexId *d_component_ids, long long nodes, VertexId *d_giant)
+{
+    __shared__ VertexId s_root[kGiantSamples];
+    __shared__ int s_best_count;
+    const int t = threadIdx.x;
+    const long long stride = nodes >= kGiantSamples ? nodes / kGiantSamples : 1;
+    const long long v = static_cast<long long>(t) * stride;
+    VertexId r = v < nodes ? d_component_ids[v] : static_cast<VertexId>(-1);
+    if (r >= 0) r = d_component_ids[r];  // (one more hop costs nothing and tolerates a vertex one jump short of its root)
+    s_root[t] = r;
+    if (t == 0) s_best_count = 0;
+    __syncthreads();
+    int count = 0;
+    if (r >= 0)
+        for (int j = 0; j < kGiantSamples; ++j) count += s_root[j] == r;
+    atomicMax(&s_best_count, count);
+    __syncthreads();
+    if (r >= 0 && count == s_best_count) {  // (several threads may hold the winning root: they write the same values)
+        d_giant[0] = r;
+        d_giant[1] = static_cast<VertexId>(count);
+    }
+    if (t == 0) {
+        d_giant[2] = 0;
+        if (s_best_count == 0) { d_giant[0] = static_cast<VertexId>(-1); d_giant[1] = 0; }
+    }
+}
+
 template <typename VertexId, typename SizeT>
 __global__ void FirstLowerKernel(const SizeT *d_low_offsets, const VertexId *d_low_tos, long long nodes, VertexId *d_first)
 {
@@ -157,6 +189,15 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         const VertexId *d_tos = nullptr;      // per edge: destination vertex (= CSR column_indices)
         int symmetric = 0;                    // every edge has its mirror: hooking sweeps need one orientation only
         const VertexId *d_first_lower = nullptr;  // compact (mirrored) layout: per vertex its smallest neighbour below it, or itself
+        // row form of the hooking sweep (mirrored input; cc_functor.hpp HookMaxRowFunctor): the whole CSR and three device words --
+        // [0] root of the sampled giant component (-1: none), [1] how many of the samples it holds, [2] raised by a vertex whose
+        // row is too long for one lane
+        const SizeT *d_row_offsets = nullptr;
+        const VertexId *d_columns = nullptr;
+        VertexId *d_giant = nullptr;
+        SizeT row_form_limit = 256;
+        const SizeT *d_low_offsets = nullptr;     // compact layout: row extents of the from > to list (the neighbour rounds read them)
+        int neighbour_round = 0;                  // which lower neighbour of every vertex a neighbour round hooks (0 = the smallest)
         int *d_vertex_flag = nullptr;         // cleared by a pointer-jump sweep that changed something
         int *d_edge_flag = nullptr;           // cleared by a hook sweep that hooked something
     };
@@ -167,7 +208,12 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
     // edges the hooking sweeps run over: all of them, or -- mirrored input -- the from > to orientation only (AllocData)
     _SizeT sweep_edges = 0;
     bool compact_mirrored = true;      // policy (tests switch it off to run the parking path)
+    bool row_form = true;              // policy: hooking sweeps in row form when a sampled component dominates (cc_functor.hpp)
     _VertexId *d_owned_first = nullptr;
+    _SizeT *d_owned_low_offsets = nullptr;
+    int neighbour_rounds = 1;          // policy: neighbour rounds in front of the row-form sweeps (0: first hooking sweep in edge form).
+                                       // Scale-24 R-MAT, whole CC: 0 -> 1.51 ms, 1 -> 0.84, 2 -> 1.11, 3 -> 1.38 (a round costs ~0.3 ms:
+                                       // 16 M random parent gathers and the jumps; the second one no longer shortens what follows)
     _VertexId *d_owned_tos = nullptr;  // the compact `to` array when the problem owns one (d_tos otherwise aliases the CSR's columns)
 
     ~CCProblem() override
@@ -187,6 +233,7 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         if (h_flags) util::GRError(hipHostFree(h_flags), "CCProblem hipHostFree failed", __FILE__, __LINE__);
         if (d_owned_tos) util::GRError(hipFree(d_owned_tos), "CCProblem hipFree failed", __FILE__, __LINE__);
         if (d_owned_first) util::GRError(hipFree(d_owned_first), "CCProblem hipFree failed", __FILE__, __LINE__);
+        if (d_owned_low_offsets) util::GRError(hipFree(d_owned_low_offsets), "CCProblem hipFree failed", __FILE__, __LINE__);
     }
 
     hipError_t AllocData()
@@ -227,6 +274,8 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
         }
         sweep_edges = this->edges;
         if (const char *env = std::getenv("GUNROCK_CC_COMPACT")) compact_mirrored = env[0] != '0';  // (tests: "0" keeps both orientations)
+        if (const char *env = std::getenv("GUNROCK_CC_ROWFORM")) row_form = env[0] != '0';
+        if (const char *env = std::getenv("GUNROCK_CC_NEIGHBOUR_ROUNDS")) neighbour_rounds = std::atoi(env);
         if (ds->symmetric && this->edges > 0 && compact_mirrored) {
             // Mirrored input: the orientation from < to would be parked at first sight by every hooking sweep (its mirror does the very
             // same hook).  Materialise only the from > to pairs -- half the edge stream for HookInit and for every HookMax sweep
@@ -262,13 +311,16 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipStreamSynchronize(gs->stream), "FirstLowerKernel failed");
             ds->d_first_lower = d_first;
             d_owned_first = d_first;
+            ds->d_row_offsets = gs->d_row_offsets;
+            ds->d_columns = gs->d_column_indices;
             GR_CHECK(hipFree(ds->d_froms), "CCProblem hipFree failed");  // the full expansion is not needed any more
             ds->d_froms = d_low_froms;
             ds->d_tos = d_low_tos;
             d_owned_tos = d_low_tos;
             sweep_edges = low_edges;
             GR_CHECK(hipFree(d_count), "CCProblem hipFree failed");
-            GR_CHECK(hipFree(d_low_offsets), "CCProblem hipFree failed");
+            ds->d_low_offsets = d_low_offsets;  // (kept: the neighbour rounds of the row form index the compact rows)
+            d_owned_low_offsets = d_low_offsets;
             GR_CHECK(hipFree(d_sums), "CCProblem hipFree failed");
         }
         return retval;
