@@ -121,7 +121,7 @@ class CCEnactor : public EnactorBase {
         //      giant component is still a forest of many trees (measured: started at the first sweep, a vertex with a long row
         //      outside the sampled tree sent the run back to the edge form at once, 1.68 -> 1.81 ms). ----
         bool row_form = false;
-        const bool row_form_wanted = m > 0 && slice.d_first_lower && problem->row_form;
+        const bool row_form_wanted = m > 0 && slice.d_first_lower && slice.d_row_offsets && problem->row_form;  // (rows: every edge mirrored)
         VertexId *d_giant = reinterpret_cast<VertexId *>(work_progress.d_tail + 4);  // slots 4, 5: mirrored by every read-back
         if (row_form_wanted) {
             slice.d_giant = d_giant;

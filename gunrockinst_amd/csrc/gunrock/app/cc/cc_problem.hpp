@@ -15,10 +15,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include <gunrock/app/problem_base.hpp>
 #include <gunrock/graphio/device_csr.hpp>
+#include <gunrock/graphio/symmetry.hpp>
 #include <gunrock/util/device_intrinsics.hpp>
 #include <gunrock/util/memset_kernel.hpp>
 
@@ -311,8 +313,21 @@ struct CCProblem : ProblemBase<_VertexId, _SizeT, _Value, _USE_DOUBLE_BUFFER> {
             GR_CHECK(hipStreamSynchronize(gs->stream), "FirstLowerKernel failed");
             ds->d_first_lower = d_first;
             d_owned_first = d_first;
-            ds->d_row_offsets = gs->d_row_offsets;
-            ds->d_columns = gs->d_column_indices;
+            // The row form lets a vertex of the giant component skip its row and relies on the OTHER end of each of its edges walking
+            // its own: that needs every edge mirrored, both orientations.  `symmetric` above is weaker (only from < to edges were
+            // checked -- enough to drop that orientation): a graph whose unmirrored edges all point from a higher to a lower id
+            // passes it, and an edge giant -> outside would then be seen by nobody.  So the exact test decides (graphio/symmetry.hpp).
+            bool fully_mirrored = false;
+            if constexpr (std::is_same<VertexId, int>::value && std::is_same<SizeT, int>::value) {
+                if (row_form)
+                    GR_CHECK(graphio::DeviceIsSymmetric(static_cast<int>(this->nodes), static_cast<long long>(this->edges), gs->d_row_offsets,
+                                                        gs->d_column_indices, gs->stream, fully_mirrored),
+                             "CCProblem symmetry test failed");
+            }
+            if (fully_mirrored) {
+                ds->d_row_offsets = gs->d_row_offsets;
+                ds->d_columns = gs->d_column_indices;
+            }
             GR_CHECK(hipFree(ds->d_froms), "CCProblem hipFree failed");  // the full expansion is not needed any more
             ds->d_froms = d_low_froms;
             ds->d_tos = d_low_tos;

@@ -145,5 +145,18 @@ def test_row_form_hooking_sweeps_skip_the_giant_component(rowform, limit, rounds
     leaves = np.arange(1, 5000, dtype=np.int32)
     hg = ga.HostGraph.from_coo(5000, np.concatenate([np.zeros(4999, np.int32), leaves]), np.concatenate([leaves, np.zeros(4999, np.int32)]))
     graphs.append(o.Csr(hg.nodes, np.array(hg.row_offsets), np.array(hg.col_indices)))  # star: the hub's row is long
+    # ... and a DIRECTED graph whose edges all point from the higher to the lower id: it passes the "every from < to edge has its mirror"
+    # test vacuously, so the compact edge list applies, but the row form must not -- vertex 1000 + k of the giant component holds the
+    # ONLY edge that ties vertex k (no out-edges, third in its row) to it
+    k = np.arange(2, 1000, dtype=np.int32)
+    rest = np.arange(1000, 3000, dtype=np.int32)
+    rows = np.concatenate([[1], rest, rest, 1000 + k]).astype(np.int32)
+    cols = np.concatenate([[0], np.zeros_like(rest), np.ones_like(rest), k]).astype(np.int32)
+    hg = ga.HostGraph.from_coo(3000, rows, cols)
+    graphs.append(o.Csr(hg.nodes, np.array(hg.row_offsets), np.array(hg.col_indices)))
+    rng = np.random.default_rng(11)
+    a, b = rng.integers(0, 40000, 150000), rng.integers(0, 40000, 150000)
+    hg = ga.HostGraph.from_coo(40000, np.maximum(a, b).astype(np.int32), np.minimum(a, b).astype(np.int32))
+    graphs.append(o.Csr(hg.nodes, np.array(hg.row_offsets), np.array(hg.col_indices)))
     for g in graphs:
         _check(g)

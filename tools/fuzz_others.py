@@ -18,8 +18,11 @@ def graph():
     rows, cols = rng.integers(0, n, m), rng.integers(0, n, m)
     if kind == 2:
         cols = np.where(rng.random(m) < 0.3, rng.integers(0, max(n // 1000, 1), m), cols)
-    if rng.integers(0, 2):
+    orient = rng.integers(0, 4)
+    if orient >= 2:
         rows, cols = np.concatenate([rows, cols]), np.concatenate([cols, rows])
+    elif orient == 1:  # every edge points from the higher to the lower id: passes any "upward edges are mirrored" test vacuously
+        rows, cols = np.maximum(rows, cols), np.minimum(rows, cols)
     hg = ga.HostGraph.from_coo(n, rows.astype(np.int32), cols.astype(np.int32))
     return o.Csr(n, np.array(hg.row_offsets), np.array(hg.col_indices))
 
