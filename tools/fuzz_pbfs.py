@@ -66,7 +66,10 @@ def worker(rank, world, port, budget, seed, out):
 
 
 if __name__ == "__main__":
-    world = int(sys.argv[1]); budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    world = int(sys.argv[1])
+    if not 1 <= world <= 5:  # (ranks share ONE GPU here; the box allows 6 processes on it -- and "fuzz_pbfs.py 90 7" meant seconds, not ranks)
+        sys.exit("usage: fuzz_pbfs.py <world 1..5> [seconds] [seed]")
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     out = "/tmp/fuzz_pbfs_%d.txt" % os.getpid()
     mp.spawn(worker, args=(world, 29000 + os.getpid() % 2000, budget, seed, out), nprocs=world, join=True)
     sys.exit(0 if open(out).read() == "ok" else 1)
