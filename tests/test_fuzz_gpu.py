@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUDGET_S = os.environ.get("GUNROCK_FUZZ_SECONDS", "25")
+BUDGET_S = os.environ.get("GUNROCK_FUZZ_SECONDS", "15")  # (per sweep; the whole GPU suite is kept near six minutes)
 
 
 def _run(script, *args, timeout=240):
